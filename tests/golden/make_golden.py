@@ -1,0 +1,274 @@
+#!/usr/bin/env python
+"""Generate the committed golden vectors by running the REAL reference (/root/reference, imported in
+place through tests/refstub.py).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Outputs (tests/golden/):
+    model_<case>.json   forward outputs, loss, gradient / post-AdamW fingerprints (full tensors for the toy case)
+    update_toy.json     FedavgClient.update() result dict + final weights fingerprint
+    agg.json            FedavgServer._aggregate outputs over the scope / compensation matrix
+    sampling.json       FedavgServer._sample_clients id lists
+    init.json           default-init state_dict fingerprints under torch.manual_seed (factory order check)
+
+Inputs and weights are NOT stored: they come from tests/synth.py's exact integer generator, so a fixture
+is only (generator seeds, expected outputs).
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from refstub import RefArgs, load_reference  # noqa: E402
+from synth import det_ids, det_state_dict, det_tensor, summarize  # noqa: E402
+
+ref = load_reference()
+torch.set_num_threads(8)
+
+# single-process restatement of torchmultimodal's ContrastiveLossWithTemperature (third party, absent):
+import math  # noqa: E402
+
+
+class ContrastiveLossWithTemperature(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.logit_scale = torch.nn.Parameter(torch.tensor(math.log(1 / 0.07)))
+
+    def forward(self, a, b):
+        self.logit_scale.data.clamp_(math.log(1.0), math.log(100.0))
+        t = torch.exp(self.logit_scale)
+        la = (a @ b.t()) * t
+        lb = (b @ a.t()) * t
+        lab = torch.arange(a.shape[0])
+        return (torch.nn.functional.cross_entropy(la, lab) + torch.nn.functional.cross_entropy(lb, lab)) / 2
+
+
+torch.nn.ContrastiveLoss = ContrastiveLossWithTemperature
+
+CASES = {
+    # name: (model kwargs, B, seq, kind)
+    "toy": dict(mk=dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=4, depth=1,
+                        num_heads=2, vocab_size=30, max_text_len=8), B=2, seq=8, kind="img+txt", full=True),
+    "small": dict(mk=dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=128, depth=2,
+                          num_heads=2, vocab_size=64, max_text_len=16), B=4, seq=16, kind="img+txt", full=False),
+    "imgcls_aux": dict(mk=dict(modalities=["img", None], num_classes=[10, None], tasks=["cls", None], embed_dim=64, depth=2,
+                               num_heads=1, vocab_size=64, max_text_len=16, with_aux=True, aux_trained=True),
+                       B=4, seq=16, kind="img", full=False),
+    "txtcls_aux": dict(mk=dict(modalities=[None, "txt"], num_classes=[None, 4], tasks=[None, "cls"], embed_dim=64, depth=2,
+                               num_heads=1, vocab_size=64, max_text_len=16, with_aux=True, aux_trained=False),
+                       B=4, seq=12, kind="txt", full=False),
+}
+
+
+def build(mk):
+    m = ref.mome.ModalityAgnosticTransformer(**mk)
+    m.sync_shared_weights()
+    sd = m.state_dict()
+    new = det_state_dict({k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict(new, strict=True)
+    return m
+
+
+def pack(t, full):
+    return dict(full=[float(x) for x in t.detach().reshape(-1)], shape=list(t.shape)) if full else summarize(t)
+
+
+def model_case(name, c):
+    m = build(c["mk"])
+    m.train()
+    B, seq, kind = c["B"], c["seq"], c["kind"]
+    img = det_tensor((B, 3, 224, 224), 1000, 0.5)
+    ids = det_ids((B, seq), 7, c["mk"]["vocab_size"])
+    y = (torch.arange(B) * 3 + 1) % (max(x for x in c["mk"]["num_classes"] if x) if kind != "img+txt" else 1)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.0)
+    opt.zero_grad()
+    if kind == "img+txt":
+        outs = m([img, ids], feat_out=True)
+        loss = torch.nn.ContrastiveLoss()(*outs)
+    elif kind == "img":
+        outs = m([img, None])
+        loss = torch.nn.CrossEntropyLoss()(outs[0], y)
+    else:
+        outs = m([None, ids])
+        loss = torch.nn.CrossEntropyLoss()(outs[1], y)
+    loss.backward()
+    rec = dict(case=name, mk=c["mk"], B=B, seq=seq, kind=kind, lr=1e-3, loss=float(loss),
+               outs=[None if o is None else pack(o, True) for o in outs], grads={}, after={})
+    for k, p in m.named_parameters():
+        rec["grads"][k] = None if p.grad is None else pack(p.grad, c["full"])
+    opt.step()
+    for k, p in m.named_parameters():
+        rec["after"][k] = pack(p, c["full"])
+    # eval-mode forward through the heads (feat_out=False) as well
+    m.eval()
+    with torch.no_grad():
+        ev = m([img if kind != "txt" else None, ids if kind != "img" else None], feat_out=False)
+    rec["eval_outs"] = [None if o is None else pack(o, True) for o in ev]
+    with open(os.path.join(HERE, f"model_{name}.json"), "w") as f:
+        json.dump(rec, f)
+    print(name, "loss", float(loss))
+
+
+class SynthPairs(torch.utils.data.Dataset):
+    def __init__(self, n, seq, vocab):
+        self.img = det_tensor((n, 3, 224, 224), 2000, 0.5)
+        self.ids = det_ids((n, seq), 11, vocab)
+
+    def __len__(self):
+        return self.img.shape[0]
+
+    def __getitem__(self, i):
+        return self.img[i], self.ids[i], i // 5, i, i
+
+
+def update_case():
+    """FedavgClient.update() on the toy img+txt model: 2 epochs x 3 batches (last one ragged)."""
+    c = CASES["toy"]
+    args = RefArgs(E=2, B=4, lr=1e-3, optimizer="AdamW", no_shuffle=True)
+    ds = SynthPairs(10, 8, 30)
+    cl = ref.fedavgclient.FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt",
+                                       eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cpu"
+    cl.download({"Flickr30k": build(c["mk"])})
+    res = cl.update()
+    sd = cl.upload()
+    rec = dict(results={str(k): v for k, v in res.items()}, n=10, B=4, E=2, lr=1e-3,
+               after={k: pack(v, True) for k, v in sd.items() if v.dtype.is_floating_point})
+    with open(os.path.join(HERE, "update_toy.json"), "w") as f:
+        json.dump(rec, f)
+    print("update", res)
+
+
+# ----------------------------------------------------------------------------------------- aggregation
+DS = {"CIFAR100": ("cls", "img"), "AG_NEWS": ("cls", "txt"), "Flickr30k": ("rtv", "img+txt")}
+
+
+def agg_models(with_aux):
+    out = {}
+    common = dict(embed_dim=4, depth=1, num_heads=2, vocab_size=30, max_text_len=8)
+    out["CIFAR100"] = ref.mome.ModalityAgnosticTransformer(modalities=["img", None], num_classes=[100, None], tasks=["cls", None],
+                                                           with_aux=with_aux, aux_trained=True, **common)
+    out["AG_NEWS"] = ref.mome.ModalityAgnosticTransformer(modalities=[None, "txt"], num_classes=[None, 4], tasks=[None, "cls"],
+                                                          with_aux=with_aux, aux_trained=True, **common)
+    out["Flickr30k"] = ref.mome.ModalityAgnosticTransformer(modalities=["img", "txt"], num_classes=[None, None],
+                                                            tasks=["rtv", "rtv"], with_aux=with_aux, aux_trained=True, **common)
+    for i, (k, m) in enumerate(out.items()):
+        sd = m.state_dict()
+        m.load_state_dict(det_state_dict({kk: tuple(v.shape) for kk, v in sd.items()}, base_seed=31 * (i + 1)))
+    return out
+
+
+class FakeClient:
+    def __init__(self, cid, dataset, model, args, n):
+        self.id, self.dataset, self.args = cid, dataset, args
+        self.task, self.modality = DS[dataset]
+        self.model = model
+        self.n = n
+    upload = ref.fedavgclient.FedavgClient.upload
+
+    def __len__(self):
+        return self.n
+
+
+def agg_case():
+    recs = []
+    # clients: 2 img, 2 txt, 2 img+txt ; sizes differ
+    layout = [(0, "CIFAR100", 50), (1, "CIFAR100", 70), (2, "AG_NEWS", 40), (3, "AG_NEWS", 90), (4, "Flickr30k", 60), (5, "Flickr30k", 30)]
+    combos = [("none", "dataset", False, False, [1, 1, 1]), ("attn", "modality", False, False, [1, 1, 1]),
+              ("attn", "modality", True, False, [1, 1, 1]), ("blocks", "all", False, False, [1, 1, 1]),
+              ("blocks", "all", True, False, [1, 1, 0.5]), ("attn", "modality", True, True, [1, 1, 1]),
+              ("blocks", "modality", False, False, [1, 0.5, 1])]
+    for shared_param, share_scope, comp, with_aux, oms in combos:
+        args = RefArgs(shared_param=shared_param, share_scope=share_scope, compensation=comp, with_aux=with_aux,
+                       aux_trained=True, datasets=list(DS.keys()), modalities=["img", "txt", "img+txt"], out_modality_scales=oms)
+        srv = object.__new__(ref.fedavgserver.FedavgServer)
+        srv.args = args
+        srv._round = 0
+        srv.global_models = agg_models(with_aux)
+        srv._init_param_scope(shared_param, share_scope)
+        clients = []
+        for cid, ds, n in layout:
+            import copy
+            m = copy.deepcopy(srv.global_models[ds])
+            sd = m.state_dict()
+            m.load_state_dict(det_state_dict({k: tuple(v.shape) for k, v in sd.items()}, base_seed=1000 + 17 * cid))
+            clients.append(FakeClient(cid, ds, m, args, n))
+        srv._clients = clients
+        ids = [0, 1, 3, 4, 5] if shared_param != "none" else [0, 1, 2, 3, 4, 5]
+        sizes = {i: clients[i].n for i in ids}
+        rec = dict(shared_param=shared_param, share_scope=share_scope, compensation=comp, with_aux=with_aux,
+                   out_modality_scales=oms, ids=ids, sizes={str(k): v for k, v in sizes.items()},
+                   layout=layout, scope=dict(srv.param_scope), result={})
+        for i, ds in enumerate(srv.global_models.keys()):
+            srv.global_model = srv.global_models[ds]
+            srv.task, srv.modality = DS[ds]
+            srv.dataset = ds
+            srv.out_modality_scale = oms[i]
+            srv._aggregate(ids, sizes)
+            rec["result"][ds] = {k: pack(v, True) for k, v in srv.global_model.state_dict().items() if v.dtype.is_floating_point}
+        recs.append(rec)
+        print("agg", shared_param, share_scope, comp, with_aux)
+    with open(os.path.join(HERE, "agg.json"), "w") as f:
+        json.dump(recs, f)
+
+
+def sampling_case():
+    recs = []
+    for seed in (1, 2, 7):
+        for equal in (True, False):
+            args = RefArgs(equal_sampled=equal, C=0.25, K=32, datasets=["CIFAR100", "AG_NEWS", "Flickr30k"])
+            srv = object.__new__(ref.fedavgserver.FedavgServer)
+            srv.args = args
+            srv._round = 0
+            srv.Cs = {"CIFAR100": 0.25, "AG_NEWS": 0.25, "Flickr30k": 0.25}
+            cl = []
+            for i in range(32):
+                o = type("C", (), {})()
+                o.id = i
+                o.dataset = "CIFAR100" if i < 12 else ("AG_NEWS" if i < 24 else "Flickr30k")
+                o.modality = "x"
+                o.device = None
+                cl.append(o)
+            srv._clients = cl
+            random.seed(seed)
+            rounds = [srv._sample_clients() for _ in range(4)]
+            recs.append(dict(seed=seed, equal_sampled=equal, rounds=rounds))
+    with open(os.path.join(HERE, "sampling.json"), "w") as f:
+        json.dump(recs, f)
+    print("sampling ok")
+
+
+def init_case():
+    recs = []
+    for name, mk in [("toy", CASES["toy"]["mk"]), ("small", CASES["small"]["mk"]), ("imgcls_aux", CASES["imgcls_aux"]["mk"]),
+                     ("txtcls_aux", CASES["txtcls_aux"]["mk"])]:
+        torch.manual_seed(1234)
+        m = ref.mome.ModalityAgnosticTransformer(**mk)
+        m.sync_shared_weights()
+        recs.append(dict(name=name, mk=mk, seed=1234,
+                         keys=[[k, list(v.shape)] for k, v in m.state_dict().items()],
+                         params=[k for k, _ in m.named_parameters()],
+                         requires_grad={k: bool(p.requires_grad) for k, p in m.named_parameters()},
+                         required=list(m.required_params().keys()),
+                         aux=list(m.aux_params().keys()) if m.with_aux else None,
+                         sd={k: summarize(v.float()) for k, v in m.state_dict().items()}))
+    with open(os.path.join(HERE, "init.json"), "w") as f:
+        json.dump(recs, f)
+    print("init ok")
+
+
+if __name__ == "__main__":
+    for n, c in CASES.items():
+        model_case(n, c)
+    update_case()
+    agg_case()
+    sampling_case()
+    init_case()
