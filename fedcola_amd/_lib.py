@@ -1,0 +1,103 @@
+"""ctypes binding of libfedcola_hip.so (the C ABI declared in include/fedcola_hip.h).
+
+The product path has no CPU or PyTorch fallback: if the HIP library is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfedcola_hip.so")
+
+FC_PREC_FP32, FC_PREC_BF16 = 0, 1
+FC_TASK_NONE, FC_TASK_CLS, FC_TASK_RTV = 0, 1, 2
+
+
+class FcModelCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "has_img", "has_txt", "img_size", "patch", "in_chans", "dim", "depth", "heads", "mlp_hidden", "vocab",
+        "max_text_len", "task_img", "task_txt", "num_classes_img", "num_classes_txt", "with_aux", "aux_trained",
+        "aux_attn_only", "aux_mlp_only", "precision")]
+
+
+class FcSegment(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("offset", C.c_int64), ("numel", C.c_int64), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4), ("trainable", C.c_int32)]
+
+
+class FedcolaHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_P = C.c_void_p
+_I = C.c_int32
+_F = C.c_float
+_L = C.c_int64
+_Z = C.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol include/fedcola_hip.h declares (tests check this).
+SIGNATURES = {
+    "fc_last_error": (C.c_char_p, []),
+    "fc_abi_version": (C.c_int, []),
+    "fc_model_create": (C.c_int, [C.POINTER(FcModelCfg), C.POINTER(_P)]),
+    "fc_model_destroy": (None, [_P]),
+    "fc_model_num_params": (_L, [_P]),
+    "fc_model_num_segments": (_I, [_P]),
+    "fc_model_segment": (C.c_int, [_P, _I, C.POINTER(FcSegment)]),
+    "fc_model_set_trainable": (C.c_int, [_P, _I, _I]),
+    "fc_workspace_bytes": (_Z, [_P, _I, _I]),
+    "fc_compute_weights_bytes": (_Z, [_P]),
+    "fc_prepare_weights": (C.c_int, [_P, _P, _P, _P]),
+    "fc_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _Z, _P, _P, _P]),
+    "fc_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "fc_contrastive_loss_fwd_bwd": (C.c_int, [_P, _P, _I, _I, _F, _P, _Z, _P, _P, _P, _P]),
+    "fc_contrastive_scratch_floats": (_Z, [_I]),
+    "fc_ce_loss_fwd_bwd": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
+    "fc_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
+    "fc_client_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _I, _P, _P, _Z, _P]),
+    "fc_aggregate_blend": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _I, _P]),
+    "fc_scale_segments": (C.c_int, [_P, _P, _P, _P, _I, _P]),
+    "fc_upload_fold": (C.c_int, [_P, _P, _P, _P]),
+    "fc_k_layernorm_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "fc_k_layernorm_bwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fc_k_gemm": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "fc_k_attention_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "fc_k_attention_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "fc_k_adamw": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
+    "fc_k_cast": (C.c_int, [_I, _P, _P, _L, _P]),
+}
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FedcolaHipError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -m fedcola_amd.build). "
+                "fedcola_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise FedcolaHipError(lib().fc_last_error().decode() or f"libfedcola_hip error {rc}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor, or None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

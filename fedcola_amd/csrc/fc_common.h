@@ -1,0 +1,92 @@
+// Common device/host helpers for the FedCola MI355X (gfx950) hot-path library.
+// CDNA4 only: 64-wide wavefronts are hard-coded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#define FC_WAVE 64
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+
+// ---------------------------------------------------------------- error handling (no exceptions across the ABI)
+void fc_set_error(const char* fmt, ...);
+#define FC_CHECK_HIP(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      fc_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return -2;                                                                            \
+    }                                                                                       \
+  } while (0)
+#define FC_REQUIRE(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      fc_set_error(__VA_ARGS__);   \
+      return -1;                   \
+    }                              \
+  } while (0)
+#define FC_LAUNCH_CHECK() FC_CHECK_HIP(hipGetLastError())
+#define FC_TRY(expr)          \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != 0) return _r;   \
+  } while (0)
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__host__ __device__ inline float bf2f(bf16_t u) {
+  union { uint32_t i; float f; } c;
+  c.i = ((uint32_t)u) << 16;
+  return c.f;
+}
+__host__ __device__ inline bf16_t f2bf(float f) {
+  union { uint32_t i; float f; } c;
+  c.f = f;
+  uint32_t u = c.i;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // keep NaN a NaN
+  return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);                // round to nearest even
+}
+
+template <typename T> struct Io;
+template <> struct Io<float> {
+  static __device__ inline float ld(const float* p, size_t i) { return p[i]; }
+  static __device__ inline void st(float* p, size_t i, float v) { p[i] = v; }
+};
+template <> struct Io<bf16_t> {
+  static __device__ inline float ld(const bf16_t* p, size_t i) { return bf2f(p[i]); }
+  static __device__ inline void st(bf16_t* p, size_t i, float v) { p[i] = f2bf(v); }
+};
+
+// ---------------------------------------------------------------- wave64 reductions (DPP/shuffle, no LDS)
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ inline float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * __expf(-0.5f * x * x) * 0.39894228040143267794f;
+}
+
+static inline int fc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- GEMM epilogue description (shared by generic + MFMA GEMMs)
+struct GemmEpi {
+  const float* bias = nullptr;      // [N] added to acc
+  const void* res = nullptr;        // residual [M,N] in the OUTPUT element type (may alias C)
+  const float* rowscale = nullptr;  // per-sample multiplier (drop-path) applied to (acc+bias) before the residual add
+  int rows_per_sample = 1;          // rowscale index = m / rows_per_sample
+  void* preact = nullptr;           // if set: store (acc+bias) here (output type) and write gelu(acc+bias) to C
+  const void* gelu_in = nullptr;    // if set: C = acc * gelu'(gelu_in[m,n])   (output type)
+  int accumulate = 0;               // C += result (fp32 C only)
+  float alpha = 1.0f;               // result = alpha*acc (+bias...)
+  int patch_rows = 0;               // >0: patch-embed remap: out row = m + m/patch_rows + 1, adds pos[1 + m%patch_rows]
+  const float* pos = nullptr;       // [1+patch_rows, N] fp32
+};

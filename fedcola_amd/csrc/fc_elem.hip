@@ -1,0 +1,526 @@
+// HBM-bound kernels of the FedCola client step for gfx950: LayerNorm, embeddings, head, losses, AdamW,
+// re-param fold, column sums, aggregation blend.  One wave (64 lanes) per row for the row-wise ops, wave-shuffle
+// reductions, 16-byte vector accesses for the flat-buffer ops.
+// Reference semantics: see fc_kernels.h / DESIGN.md (each launcher cites the reference lines it replaces).
+#include "fc_kernels.h"
+
+
+// ======================================================================== LayerNorm (mome.py:199,203,215,751; K3)
+template <typename T>
+__global__ void __launch_bounds__(256) k_ln_fwd(const T* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const T* xr = x + (size_t)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += Io<T>::ld(xr, i);
+  float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = lane; i < D; i += 64) { float d = Io<T>::ld(xr, i) - mu; q += d * d; }
+  float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  T* yr = y + (size_t)row * D;
+  for (int i = lane; i < D; i += 64) Io<T>::st(yr, i, (Io<T>::ld(xr, i) - mu) * rs * g[i] + b[i]);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int D,
+                     float eps, hipStream_t s) {
+  if (M <= 0) return 0;
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_fwd<T>, dim3(fc_cdiv(M, 4)), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, M, D, eps));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// rows handled per block in the backward (dg/db partials are reduced in-block, then one atomic per column per block)
+#define LNB_ROWS 32
+#define LNB_MAXV 16  // D <= 64*16
+template <typename T>
+__global__ void __launch_bounds__(256) k_ln_bwd(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                                const float* __restrict__ rstd, const float* __restrict__ g, const T* res, T* dx,
+                                                float* __restrict__ dg, float* __restrict__ db, int M, int D) {
+  __shared__ float red[2][4][64 * LNB_MAXV > 1024 ? 1024 : 64 * LNB_MAXV];  // [dg|db][wave][col]
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float ag[LNB_MAXV], ab[LNB_MAXV];
+#pragma unroll
+  for (int t = 0; t < LNB_MAXV; ++t) { ag[t] = 0.f; ab[t] = 0.f; }
+  int row0 = blockIdx.x * LNB_ROWS;
+  for (int r = wave; r < LNB_ROWS; r += 4) {
+    int row = row0 + r;
+    if (row >= M) break;
+    const T* dyr = dy + (size_t)row * D;
+    const T* xr = x + (size_t)row * D;
+    float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < LNB_MAXV; ++t) {
+      int i = lane + 64 * t;
+      if (i < D) {
+        float d = Io<T>::ld(dyr, i), xh = (Io<T>::ld(xr, i) - mu) * rs;
+        float dxh = d * g[i];
+        s1 += dxh; s2 += dxh * xh;
+        ag[t] += d * xh; ab[t] += d;
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    T* dxr = dx + (size_t)row * D;
+#pragma unroll
+    for (int t = 0; t < LNB_MAXV; ++t) {
+      int i = lane + 64 * t;
+      if (i < D) {
+        float d = Io<T>::ld(dyr, i), xh = (Io<T>::ld(xr, i) - mu) * rs;
+        float v = rs * (d * g[i] - s1 - xh * s2);
+        if (res) v += Io<T>::ld(res + (size_t)row * D, i);
+        Io<T>::st(dxr, i, v);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < LNB_MAXV; ++t) {
+    int i = lane + 64 * t;
+    if (i < D) { red[0][wave][i] = ag[t]; red[1][wave][i] = ab[t]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) {
+    float a = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
+    float c = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
+    atomicAdd(dg + i, a);
+    atomicAdd(db + i, c);
+  }
+}
+
+int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res,
+                     void* dx, float* dg, float* db, int M, int D, hipStream_t s) {
+  if (M <= 0) return 0;
+  FC_REQUIRE(D <= 64 * LNB_MAXV, "layernorm_bwd: D=%d > %d unsupported", D, 64 * LNB_MAXV);
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(fc_cdiv(M, LNB_ROWS)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, g,
+                                     (const T*)res, (T*)dx, dg, db, M, D));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ======================================================================== image embedding (mome.py:597-611, 260-266; K1)
+// patches[(b*np + py*gw + px), c*P*P + ph*P + pw] = img[b, c, py*P+ph, px*P+pw]
+template <typename T>
+__global__ void __launch_bounds__(256) k_patchify(const float* __restrict__ img, T* __restrict__ out, int B, int C, int HW, int P) {
+  int gw = HW / P, np = gw * gw, K = C * P * P;
+  size_t total = (size_t)B * np * K;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    int k = (int)(idx % K);
+    size_t r = idx / K;
+    int p = (int)(r % np), b = (int)(r / np);
+    int c = k / (P * P), ph = (k / P) % P, pw = k % P;
+    int py = p / gw, px = p % gw;
+    Io<T>::st(out, idx, img[(((size_t)b * C + c) * HW + (py * P + ph)) * HW + px * P + pw]);
+  }
+}
+int fc_patchify(int dt, const float* img, void* patches, int B, int C, int HW, int P, hipStream_t s) {
+  size_t total = (size_t)B * (HW / P) * (HW / P) * C * P * P;
+  int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_patchify<T>, dim3(grid), dim3(256), 0, s, img, (T*)patches, B, C, HW, P));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+__global__ void k_cls_rows(const float* __restrict__ cls, const float* __restrict__ pos, T* __restrict__ x, int B, int N, int D) {
+  int b = blockIdx.x;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) Io<T>::st(x + (size_t)b * N * D, i, cls[i] + pos[i]);
+}
+int fc_cls_rows(int dt, const float* cls, const float* pos, void* x, int B, int N, int D, hipStream_t s) {
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_cls_rows<T>, dim3(B), dim3(128), 0, s, cls, pos, (T*)x, B, N, D));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// dpos[n,i] += sum_b dx[b,n,i]; dcls[i] += sum_b dx[b,0,i]; dtok[b*(N-1)+n-1, i] = dx[b,n,i]
+template <typename T>
+__global__ void __launch_bounds__(256) k_img_embed_bwd(const T* __restrict__ dx, float* __restrict__ dpos, float* __restrict__ dcls,
+                                                       T* __restrict__ dtok, int B, int N, int D) {
+  int n = blockIdx.x;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      T raw = dx[((size_t)b * N + n) * D + i];
+      s += Io<T>::ld(&raw, 0);
+      if (n > 0) dtok[((size_t)b * (N - 1) + (n - 1)) * D + i] = raw;
+    }
+    atomicAdd(dpos + (size_t)n * D + i, s);
+    if (n == 0) atomicAdd(dcls + i, s);
+  }
+}
+int fc_img_embed_bwd(int dt, const void* dx, float* dpos, float* dcls, void* dtok, int B, int N, int D, hipStream_t s) {
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_img_embed_bwd<T>, dim3(N), dim3(256), 0, s, (const T*)dx, dpos, dcls, (T*)dtok, B, N, D));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ======================================================================== text embedding (mome.py:632-639 -> HF BertEmbeddings; K2)
+__device__ inline long clamp_id(long id, int vocab) { return id < 0 ? 0 : (id >= vocab ? vocab - 1 : id); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_txt_embed_fwd(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                       const float* __restrict__ pos, const float* __restrict__ type,
+                                                       const float* __restrict__ g, const float* __restrict__ b, T* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int B, int N, int D, int vocab,
+                                                       float eps) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * N) return;
+  int n = row % N;
+  const float* w = word + (size_t)clamp_id(ids[row], vocab) * D;
+  const float* pp = pos + (size_t)n * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += w[i] + type[i] + pp[i];
+  float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = lane; i < D; i += 64) { float d = w[i] + type[i] + pp[i] - mu; q += d * d; }
+  float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  for (int i = lane; i < D; i += 64) Io<T>::st(y + (size_t)row * D, i, (w[i] + type[i] + pp[i] - mu) * rs * g[i] + b[i]);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+int fc_txt_embed_fwd(int dt, const int64_t* ids, const float* word, const float* pos, const float* type, const float* g, const float* b,
+                     void* y, float* mean, float* rstd, int B, int N, int D, int vocab, float eps, hipStream_t s) {
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_txt_embed_fwd<T>, dim3(fc_cdiv((long)B * N, 4)), dim3(256), 0, s, ids, word, pos, type, g, b, (T*)y,
+                                     mean, rstd, B, N, D, vocab, eps));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// de = LNbwd(dy) per row; dword[id] += de (id != 0: padding_idx row gets no grad); dpos[n] += de; dtype[0] += de; dg/db
+template <typename T>
+__global__ void __launch_bounds__(256) k_txt_embed_bwd(const T* __restrict__ dy, const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                       const float* __restrict__ pos, const float* __restrict__ type,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ g, float* dword, float* dpos, float* dtype, float* dg,
+                                                       float* db, int B, int N, int D, int vocab) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * N) return;
+  int n = row % N;
+  long id = clamp_id(ids[row], vocab);
+  const float* w = word + (size_t)id * D;
+  const float* pp = pos + (size_t)n * D;
+  float mu = mean[row], rs = rstd[row];
+  const T* dyr = dy + (size_t)row * D;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    float d = Io<T>::ld(dyr, i), xh = (w[i] + type[i] + pp[i] - mu) * rs;
+    s1 += d * g[i]; s2 += d * g[i] * xh;
+  }
+  s1 = wave_sum(s1) / (float)D;
+  s2 = wave_sum(s2) / (float)D;
+  for (int i = lane; i < D; i += 64) {
+    float d = Io<T>::ld(dyr, i), xh = (w[i] + type[i] + pp[i] - mu) * rs;
+    float de = rs * (d * g[i] - s1 - xh * s2);
+    if (id != 0) atomicAdd(dword + (size_t)id * D + i, de);
+    atomicAdd(dpos + (size_t)n * D + i, de);
+    atomicAdd(dtype + i, de);
+    atomicAdd(dg + i, d * xh);
+    atomicAdd(db + i, d);
+  }
+}
+int fc_txt_embed_bwd(int dt, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type, const float* mean,
+                     const float* rstd, const float* g, float* dword, float* dpos, float* dtype, float* dg, float* db, int B, int N, int D,
+                     int vocab, hipStream_t s) {
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_txt_embed_bwd<T>, dim3(fc_cdiv((long)B * N, 4)), dim3(256), 0, s, (const T*)dy, ids, word, pos, type,
+                                     mean, rstd, g, dword, dpos, dtype, dg, db, B, N, D, vocab));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ======================================================================== head: final LN on cls rows (+ L2 normalise) (mome.py:906,915,657-659; K10)
+template <typename T>
+__global__ void __launch_bounds__(64) k_head_fwd(const T* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b, float* f,
+                                                 float* mean, float* rstd, float* nrm, float* out, int B, int N, int D, float eps,
+                                                 int normalize) {
+  int bi = blockIdx.x, lane = threadIdx.x;
+  const T* xr = x + (size_t)bi * N * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += Io<T>::ld(xr, i);
+  float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = lane; i < D; i += 64) { float d = Io<T>::ld(xr, i) - mu; q += d * d; }
+  float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float n2 = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    float v = (Io<T>::ld(xr, i) - mu) * rs * g[i] + b[i];
+    f[(size_t)bi * D + i] = v;
+    n2 += v * v;
+  }
+  float nr = sqrtf(wave_sum(n2));
+  if (normalize)
+    for (int i = lane; i < D; i += 64) out[(size_t)bi * D + i] = f[(size_t)bi * D + i] / nr;
+  if (lane == 0) { mean[bi] = mu; rstd[bi] = rs; nrm[bi] = nr; }
+}
+int fc_head_fwd(int dt, const void* x, const float* g, const float* b, float* f, float* mean, float* rstd, float* nrm, float* out, int B,
+                int N, int D, float eps, int normalize, hipStream_t s) {
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_head_fwd<T>, dim3(B), dim3(64), 0, s, (const T*)x, g, b, f, mean, rstd, nrm, out, B, N, D, eps, normalize));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_head_bwd(const float* __restrict__ din, const float* __restrict__ out, const float* __restrict__ nrm,
+                                                  int normalize, const T* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ g, T* __restrict__ dx, float* dg,
+                                                  float* db, int B, int N, int D) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * N) return;
+  T* dxr = dx + (size_t)row * D;
+  if (row % N != 0) {
+    for (int i = lane; i < D; i += 64) Io<T>::st(dxr, i, 0.f);
+    return;
+  }
+  int bi = row / N;
+  const float* dr = din + (size_t)bi * D;
+  float dot = 0.f, inv = 1.f;
+  if (normalize) {
+    const float* o = out + (size_t)bi * D;
+    for (int i = lane; i < D; i += 64) dot += o[i] * dr[i];
+    dot = wave_sum(dot);
+    inv = 1.0f / nrm[bi];
+  }
+  const T* xr = x + (size_t)row * D;
+  float mu = mean[bi], rs = rstd[bi];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    float df = normalize ? (dr[i] - out[(size_t)bi * D + i] * dot) * inv : dr[i];
+    float xh = (Io<T>::ld(xr, i) - mu) * rs;
+    s1 += df * g[i]; s2 += df * g[i] * xh;
+  }
+  s1 = wave_sum(s1) / (float)D;
+  s2 = wave_sum(s2) / (float)D;
+  for (int i = lane; i < D; i += 64) {
+    float df = normalize ? (dr[i] - out[(size_t)bi * D + i] * dot) * inv : dr[i];
+    float xh = (Io<T>::ld(xr, i) - mu) * rs;
+    Io<T>::st(dxr, i, rs * (df * g[i] - s1 - xh * s2));
+    atomicAdd(dg + i, df * xh);
+    atomicAdd(db + i, df);
+  }
+}
+int fc_head_bwd(int dt, const float* din, const float* out, const float* nrm, int normalize, const void* x, const float* mean,
+                const float* rstd, const float* g, void* dx, float* dg, float* db, int B, int N, int D, hipStream_t s) {
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_head_bwd<T>, dim3(fc_cdiv((long)B * N, 4)), dim3(256), 0, s, din, out, nrm, normalize, (const T*)x,
+                                     mean, rstd, g, (T*)dx, dg, db, B, N, D));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ======================================================================== contrastive loss (torchmultimodal ContrastiveLossWithTemperature; K11)
+// scratch: L[B*B] | dL[B*B] | lse_r[B] | lse_c[B]
+__global__ void __launch_bounds__(64) k_con_lse(const float* __restrict__ L, float* lse_r, float* lse_c, float* lossbuf, int B) {
+  int idx = blockIdx.x, lane = threadIdx.x;
+  bool isrow = idx < B;
+  int i = isrow ? idx : idx - B;
+  float mx = -INFINITY;
+  for (int j = lane; j < B; j += 64) mx = fmaxf(mx, isrow ? L[(size_t)i * B + j] : L[(size_t)j * B + i]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < B; j += 64) s += expf((isrow ? L[(size_t)i * B + j] : L[(size_t)j * B + i]) - mx);
+  s = wave_sum(s);
+  float lse = mx + logf(s);
+  if (lane == 0) {
+    (isrow ? lse_r : lse_c)[i] = lse;
+    float contrib = 0.5f * (lse - L[(size_t)i * B + i]) / (float)B;
+    atomicAdd(lossbuf + 1, contrib);
+    atomicAdd(lossbuf + 0, contrib * (float)B);
+  }
+}
+__global__ void __launch_bounds__(256) k_con_dl(const float* __restrict__ L, const float* __restrict__ lse_r, const float* __restrict__ lse_c,
+                                                float* __restrict__ dL, int B) {
+  size_t n = (size_t)B * B;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+    int i = (int)(idx / B), j = (int)(idx % B);
+    float l = L[idx];
+    dL[idx] = (0.5f / (float)B) * (expf(l - lse_r[i]) + expf(l - lse_c[j]) - (i == j ? 2.0f : 0.0f));
+  }
+}
+int fc_contrastive_fwd_bwd(const float* a, const float* b, int B, int D, float tau, float* scratch, float* lossbuf, float* da, float* db,
+                           hipStream_t s) {
+  float* L = scratch;
+  float* dL = scratch + (size_t)B * B;
+  float* lse_r = dL + (size_t)B * B;
+  float* lse_c = lse_r + B;
+  GemmEpi e;
+  e.alpha = tau;
+  FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, a, D, 1, b, 1, D, L, B, B, B, D, e, s));                // L = tau * a b^T
+  hipLaunchKernelGGL(k_con_lse, dim3(2 * B), dim3(64), 0, s, L, lse_r, lse_c, lossbuf, B);
+  FC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_con_dl, dim3(fc_cdiv((long)B * B, 256)), dim3(256), 0, s, L, lse_r, lse_c, dL, B);
+  FC_LAUNCH_CHECK();
+  FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, dL, B, 1, b, D, 1, da, D, B, D, B, e, s));              // da = tau * dL b
+  FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, dL, 1, B, a, D, 1, db, D, B, D, B, e, s));              // db = tau * dL^T a
+  return 0;
+}
+
+// ======================================================================== cross entropy (fedavgclient.py:85,90; K12)
+__global__ void __launch_bounds__(64) k_ce(const float* __restrict__ logits, const int64_t* __restrict__ y, int B, int C, float* lossbuf,
+                                           float* __restrict__ dl) {
+  int i = blockIdx.x, lane = threadIdx.x;
+  const float* lr = logits + (size_t)i * C;
+  float mx = -INFINITY;
+  for (int j = lane; j < C; j += 64) mx = fmaxf(mx, lr[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < C; j += 64) s += expf(lr[j] - mx);
+  s = wave_sum(s);
+  float lse = mx + logf(s);
+  int yi = (int)y[i];
+  for (int j = lane; j < C; j += 64) dl[(size_t)i * C + j] = (expf(lr[j] - lse) - (j == yi ? 1.f : 0.f)) / (float)B;
+  if (lane == 0) {
+    float c = (lse - lr[yi]) / (float)B;
+    atomicAdd(lossbuf + 1, c);
+    atomicAdd(lossbuf + 0, c * (float)B);
+  }
+}
+int fc_ce_fwd_bwd(const float* logits, const int64_t* y, int B, int C, float* lossbuf, float* dlogits, hipStream_t s) {
+  hipLaunchKernelGGL(k_ce, dim3(B), dim3(64), 0, s, logits, y, B, C, lossbuf, dlogits);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ======================================================================== AdamW (fedavgclient.py:63,100 -> torch.optim.AdamW; K13)
+__global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                               size_t n, float decay, float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt,
+                                               bf16_t* __restrict__ shadow, int zero_grad) {
+  size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 pp = ((float4*)p)[i], gg = ((float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+    float* P = (float*)&pp; float* G = (float*)&gg; float* Mm = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = P[k] * decay;
+      Mm[k] = Mm[k] + (G[k] - Mm[k]) * (1.0f - beta1);            // exp_avg.lerp_(grad, 1-beta1)
+      V[k] = V[k] * beta2 + (1.0f - beta2) * G[k] * G[k];
+      float denom = sqrtf(V[k]) * inv_bc2_sqrt + eps;
+      P[k] = pk - step_size * (Mm[k] / denom);
+    }
+    ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+    if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (shadow) {
+      ushort4 sh; sh.x = f2bf(P[0]); sh.y = f2bf(P[1]); sh.z = f2bf(P[2]); sh.w = f2bf(P[3]);
+      ((ushort4*)shadow)[i] = sh;
+    }
+  }
+}
+int fc_adamw(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd, int step,
+             void* shadow_bf16, int zero_grad, hipStream_t s) {
+  FC_REQUIRE(n % 4 == 0 && ((uintptr_t)p % 16 == 0), "adamw: buffer must be 16B aligned and a multiple of 4 elements");
+  double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  float step_size = (float)((double)lr / bc1);
+  float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  float decay = (float)(1.0 - (double)lr * (double)wd);
+  size_t n4 = n / 4;
+  int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, s, p, g, m, v, n, decay, beta1, beta2, eps, step_size, inv_bc2_sqrt,
+                     (bf16_t*)shadow_bf16, zero_grad);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_cast(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) Io<T>::st(dst, i, src[i]);
+}
+int fc_cast(int dt_out, const float* src, void* dst, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  DISPATCH_DT(dt_out, hipLaunchKernelGGL(k_cast<T>, dim3(grid), dim3(256), 0, s, src, (T*)dst, n));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ======================================================================== CrossModalReparamLinear (mome.py:58-60; K9)
+template <typename T>
+__global__ void __launch_bounds__(256) k_reparam_fold(const float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ sc,
+                                                      T* __restrict__ dst, size_t n) {
+  float s = sc[0];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) Io<T>::st(dst, i, W[i] + s * A[i]);
+}
+int fc_reparam_fold(int dt, const float* W, const float* A, const float* scale, void* dst, size_t n, hipStream_t s) {
+  int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_reparam_fold<T>, dim3(grid), dim3(256), 0, s, W, A, scale, (T*)dst, n));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_reparam_grad(const float* __restrict__ gW, const float* __restrict__ A, const float* __restrict__ sc,
+                                                      float* ds, float* __restrict__ gA, size_t n) {
+  __shared__ float red[4];
+  float s = sc[0], acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float gw = gW[i];
+    acc += gw * A[i];
+    if (gA) gA[i] += s * gw;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(ds, red[0] + red[1] + red[2] + red[3]);
+}
+int fc_reparam_grad(const float* gW, const float* A, const float* scale, float* ds, float* gA, size_t n, hipStream_t s) {
+  int grid = (int)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_reparam_grad, dim3(grid), dim3(256), 0, s, gW, A, scale, ds, gA, n);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ======================================================================== column sums (bias gradients)
+// grid: (ceil(N/64), row-chunks); each block sums 64 columns over its row chunk, 4 waves stride rows; atomics across chunks
+template <typename T>
+__global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ dy, float* __restrict__ db, int M, int N, int rows_per_block) {
+  __shared__ float red[4][64];
+  int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float acc = 0.f;
+  if (col < N)
+    for (int r = r0 + wave; r < r1; r += 4) acc += Io<T>::ld(dy, (size_t)r * N + col);
+  red[wave][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (wave == 0 && col < N) atomicAdd(db + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+int fc_colsum(int dt, const void* dy, float* db, int M, int N, int accumulate, hipStream_t s) {
+  if (!accumulate) FC_CHECK_HIP(hipMemsetAsync(db, 0, sizeof(float) * N, s));
+  if (M <= 0) return 0;
+  int rpb = 256;
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_colsum<T>, dim3(fc_cdiv(N, 64), fc_cdiv(M, rpb)), dim3(256), 0, s, (const T*)dy, db, M, N, rpb));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ======================================================================== aggregation blend (fedavgserver.py:656-664 closed form; K14)
+__global__ void __launch_bounds__(256) k_blend(float* __restrict__ out, const float* __restrict__ g, const float* const* __restrict__ thetas, int m,
+                                               const int64_t* __restrict__ seg_off, const int64_t* __restrict__ seg_len,
+                                               const float* __restrict__ seg_w) {
+  int sgi = blockIdx.y;
+  int64_t off = seg_off[sgi], len = seg_len[sgi];
+  const float* w = seg_w + (size_t)sgi * (m + 1);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+    float acc = w[0] * g[off + i];
+    for (int j = 0; j < m; ++j) {
+      float wj = w[1 + j];
+      if (wj != 0.f) acc += wj * thetas[j][off + i];
+    }
+    out[off + i] = acc;
+  }
+}
+int fc_blend_segments(float* out, const float* g, const float* const* thetas, int m, const int64_t* seg_off, const int64_t* seg_len,
+                      const float* seg_w, int nseg, hipStream_t s) {
+  if (nseg <= 0) return 0;
+  hipLaunchKernelGGL(k_blend, dim3(64, nseg), dim3(256), 0, s, out, g, thetas, m, seg_off, seg_len, seg_w);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_scale_seg(float* __restrict__ buf, const int64_t* __restrict__ seg_off, const int64_t* __restrict__ seg_len,
+                                                   const float* __restrict__ seg_w) {
+  int sgi = blockIdx.y;
+  int64_t off = seg_off[sgi], len = seg_len[sgi];
+  float w = seg_w[sgi];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) buf[off + i] *= w;
+}
+int fc_scale_segments_impl(float* buf, const int64_t* seg_off, const int64_t* seg_len, const float* seg_w, int nseg, hipStream_t s) {
+  if (nseg <= 0) return 0;
+  hipLaunchKernelGGL(k_scale_seg, dim3(64, nseg), dim3(256), 0, s, buf, seg_off, seg_len, seg_w);
+  FC_LAUNCH_CHECK();
+  return 0;
+}

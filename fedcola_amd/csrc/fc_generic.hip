@@ -1,0 +1,268 @@
+// Shape-agnostic HIP kernels: strided GEMM (fp32 accumulate on the VALU) and exact-softmax attention fwd/bwd.
+// These run the fp32 parity mode and any configuration the MFMA fast path does not cover (toy widths, odd head
+// dims).  They are device code like everything else on the path -- there is no CPU fallback anywhere.
+#include "fc_kernels.h"
+
+// ======================================================================== generic GEMM
+// 64x64 output tile, BK=16, 256 threads, 4x4 register block per thread, LDS tiles stored k-major.
+#define GT 64
+#define GK 16
+
+template <typename TC>
+__device__ inline void epi_store(TC* C, long ldc, int m, int n, float acc, const GemmEpi& e, int M, int N) {
+  float v = acc * e.alpha;
+  if (e.bias) v += e.bias[n];
+  long orow = m;
+  if (e.patch_rows > 0) {
+    orow = (long)m + m / e.patch_rows + 1;
+    v += e.pos[(size_t)(1 + m % e.patch_rows) * N + n];
+  }
+  size_t oidx = (size_t)orow * ldc + n;
+  if (e.preact) {
+    Io<TC>::st((TC*)e.preact, oidx, v);
+    v = gelu_erf(v);
+  }
+  if (e.gelu_in) v *= gelu_erf_grad(Io<TC>::ld((const TC*)e.gelu_in, oidx));
+  if (e.rowscale) v *= e.rowscale[m / e.rows_per_sample];
+  if (e.res) v += Io<TC>::ld((const TC*)e.res, oidx);
+  if (e.accumulate) v += Io<TC>::ld(C, oidx);
+  Io<TC>::st(C, oidx, v);
+}
+
+template <typename TA, typename TB, typename TC>
+__global__ void __launch_bounds__(256) k_gemm_generic(const TA* __restrict__ A, long sam, long sak, const TB* __restrict__ Bm, long sbk, long sbn,
+                                                      TC* C, long ldc, int M, int N, int K, GemmEpi e) {
+  __shared__ float As[GK][GT + 4];
+  __shared__ float Bs[GK][GT + 4];
+  int tid = threadIdx.x;
+  int tx = tid & 15, ty = tid >> 4;
+  int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
+  for (int k0 = 0; k0 < K; k0 += GK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e_ = tid + 256 * i;  // 0..1023
+      int mm, kk;
+      if (a_kfast) { kk = e_ & 15; mm = e_ >> 4; } else { mm = e_ & 63; kk = e_ >> 6; }
+      int gm = m0 + mm, gk = k0 + kk;
+      As[kk][mm] = (gm < M && gk < K) ? Io<TA>::ld(A, (size_t)gm * sam + (size_t)gk * sak) : 0.f;
+      int nn, kb;
+      if (b_kfast) { kb = e_ & 15; nn = e_ >> 4; } else { nn = e_ & 63; kb = e_ >> 6; }
+      int gn = n0 + nn, gkb = k0 + kb;
+      Bs[kb][nn] = (gn < N && gkb < K) ? Io<TB>::ld(Bm, (size_t)gkb * sbk + (size_t)gn * sbn) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int n = n0 + tx * 4 + j;
+      if (n < N) epi_store<TC>(C, ldc, m, n, acc[i][j], e, M, N);
+    }
+  }
+}
+
+int fc_gemm_generic(int dtA, int dtB, int dtC, const void* A, long sam, long sak, const void* Bm, long sbk, long sbn, void* C, long ldc, int M,
+                    int N, int K, const GemmEpi& epi, hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  dim3 grid(fc_cdiv(N, GT), fc_cdiv(M, GT)), block(256);
+#define GG(TA, TB, TC) hipLaunchKernelGGL((k_gemm_generic<TA, TB, TC>), grid, block, 0, s, (const TA*)A, sam, sak, (const TB*)Bm, sbk, sbn, (TC*)C, ldc, M, N, K, epi)
+  if (dtA == FC_F32 && dtB == FC_F32 && dtC == FC_F32) GG(float, float, float);
+  else if (dtA == FC_BF16 && dtB == FC_BF16 && dtC == FC_BF16) GG(bf16_t, bf16_t, bf16_t);
+  else if (dtA == FC_BF16 && dtB == FC_BF16 && dtC == FC_F32) GG(bf16_t, bf16_t, float);
+  else if (dtA == FC_F32 && dtB == FC_BF16 && dtC == FC_F32) GG(float, bf16_t, float);
+  else if (dtA == FC_F32 && dtB == FC_F32 && dtC == FC_BF16) GG(float, float, bf16_t);
+  else { fc_set_error("gemm_generic: unsupported dtype combo %d %d %d", dtA, dtB, dtC); return -1; }
+#undef GG
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ======================================================================== generic attention (mome.py:150-168; K5)
+// One wave per query row.  Scores in fp32 (the reference forces q.float() @ k.float()), exact softmax.
+#define AT_MAXT 16  // N <= 64*16 keys
+template <typename T>
+__global__ void __launch_bounds__(256) k_attn_fwd(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse, int B, int N, int H, int d,
+                                                  float scale) {
+  extern __shared__ float smem[];  // per wave: q[d] | p[N]
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + wave;  // over B*H*N
+  if (row >= (long)B * H * N) return;
+  int i = (int)(row % N), h = (int)((row / N) % H), b = (int)(row / ((long)N * H));
+  float* qs = smem + (size_t)wave * (d + N);
+  float* ps = qs + d;
+  int D3 = 3 * H * d;
+  const T* base = qkv + (size_t)b * N * D3;
+  for (int t = lane; t < d; t += 64) qs[t] = Io<T>::ld(base, (size_t)i * D3 + h * d + t) * scale;
+  __builtin_amdgcn_wave_barrier();
+  float sc[AT_MAXT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < AT_MAXT; ++t) {
+    int j = lane + 64 * t;
+    sc[t] = -INFINITY;
+    if (j < N) {
+      const T* kr = base + (size_t)j * D3 + H * d + h * d;
+      float s = 0.f;
+      for (int c = 0; c < d; ++c) s = fmaf(qs[c], Io<T>::ld(kr, c), s);
+      sc[t] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < AT_MAXT; ++t) {
+    int j = lane + 64 * t;
+    if (j < N) { float p = expf(sc[t] - mx); sc[t] = p; sum += p; }
+  }
+  sum = wave_sum(sum);
+  float inv = 1.0f / sum;
+#pragma unroll
+  for (int t = 0; t < AT_MAXT; ++t) {
+    int j = lane + 64 * t;
+    if (j < N) ps[j] = sc[t] * inv;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < d; c += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < N; ++j) acc = fmaf(ps[j], Io<T>::ld(base, (size_t)j * D3 + 2 * H * d + h * d + c), acc);
+    Io<T>::st(o, ((size_t)b * N + i) * (H * d) + h * d + c, acc);
+  }
+  if (lane == 0) lse[row] = mx + logf(sum);
+}
+
+int fc_attn_fwd_generic(int dt, const void* qkv, void* o, float* lse, int B, int N, int H, int d, float scale, hipStream_t s) {
+  FC_REQUIRE(N <= 64 * AT_MAXT, "attn_generic: N=%d > %d unsupported", N, 64 * AT_MAXT);
+  size_t sh = (size_t)4 * (d + N) * sizeof(float);
+  long rows = (long)B * H * N;
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_attn_fwd<T>, dim3(fc_cdiv(rows, 4)), dim3(256), sh, s, (const T*)qkv, (T*)o, lse, B, N, H, d, scale));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+// delta[row] = sum_c dO[row,c] * O[row,c]   (row over B*H*N, layout [B,H,N])
+template <typename T>
+__global__ void __launch_bounds__(256) k_attn_delta(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta, int B, int N, int H,
+                                                    int d) {
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + wave;
+  if (row >= (long)B * H * N) return;
+  int i = (int)(row % N), h = (int)((row / N) % H), b = (int)(row / ((long)N * H));
+  size_t off = ((size_t)b * N + i) * (H * d) + h * d;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += Io<T>::ld(o, off + c) * Io<T>::ld(dout, off + c);
+  s = wave_sum(s);
+  if (lane == 0) delta[row] = s;
+}
+
+// dq: one wave per query row.  dS_ij = p_ij*(dP_ij - delta_i);  dq_i = scale * sum_j dS_ij k_j
+template <typename T>
+__global__ void __launch_bounds__(256) k_attn_bwd_q(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                    const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, int H, int d, float scale) {
+  extern __shared__ float smem[];  // per wave: q[d] | do[d] | ds[N]
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + wave;
+  if (row >= (long)B * H * N) return;
+  int i = (int)(row % N), h = (int)((row / N) % H), b = (int)(row / ((long)N * H));
+  float* qs = smem + (size_t)wave * (2 * d + N);
+  float* dos = qs + d;
+  float* dss = dos + d;
+  int D3 = 3 * H * d, Dm = H * d;
+  const T* base = qkv + (size_t)b * N * D3;
+  for (int t = lane; t < d; t += 64) {
+    qs[t] = Io<T>::ld(base, (size_t)i * D3 + h * d + t) * scale;
+    dos[t] = Io<T>::ld(dout, ((size_t)b * N + i) * Dm + h * d + t);
+  }
+  __builtin_amdgcn_wave_barrier();
+  float L = lse[row], dl = delta[row];
+  for (int j = lane; j < N; j += 64) {
+    const T* kr = base + (size_t)j * D3 + Dm + h * d;
+    const T* vr = base + (size_t)j * D3 + 2 * Dm + h * d;
+    float s = 0.f, dp = 0.f;
+    for (int c = 0; c < d; ++c) { s = fmaf(qs[c], Io<T>::ld(kr, c), s); dp = fmaf(dos[c], Io<T>::ld(vr, c), dp); }
+    dss[j] = expf(s - L) * (dp - dl);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < d; c += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < N; ++j) acc = fmaf(dss[j], Io<T>::ld(base, (size_t)j * D3 + Dm + h * d + c), acc);
+    Io<T>::st(dqkv, ((size_t)b * N + i) * D3 + h * d + c, acc * scale);
+  }
+}
+
+// dk, dv: one wave per key row j.  dv_j = sum_i p_ij dO_i ;  dk_j = sum_i dS_ij * (scale*q_i)
+template <typename T>
+__global__ void __launch_bounds__(256) k_attn_bwd_kv(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                     const float* __restrict__ delta, T* __restrict__ dqkv, int B, int N, int H, int d, float scale) {
+  extern __shared__ float smem[];  // per wave: k[d] | v[d] | p[N] | ds[N]
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + wave;
+  if (row >= (long)B * H * N) return;
+  int j = (int)(row % N), h = (int)((row / N) % H), b = (int)(row / ((long)N * H));
+  float* ks = smem + (size_t)wave * (2 * d + 2 * N);
+  float* vs = ks + d;
+  float* ps = vs + d;
+  float* dss = ps + N;
+  int D3 = 3 * H * d, Dm = H * d;
+  const T* base = qkv + (size_t)b * N * D3;
+  for (int t = lane; t < d; t += 64) {
+    ks[t] = Io<T>::ld(base, (size_t)j * D3 + Dm + h * d + t);
+    vs[t] = Io<T>::ld(base, (size_t)j * D3 + 2 * Dm + h * d + t);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float* lse_bh = lse + ((size_t)b * H + h) * N;
+  const float* del_bh = delta + ((size_t)b * H + h) * N;
+  for (int i = lane; i < N; i += 64) {
+    const T* qr = base + (size_t)i * D3 + h * d;
+    const T* dor = dout + ((size_t)b * N + i) * Dm + h * d;
+    float s = 0.f, dp = 0.f;
+    for (int c = 0; c < d; ++c) { s = fmaf(Io<T>::ld(qr, c) * scale, ks[c], s); dp = fmaf(Io<T>::ld(dor, c), vs[c], dp); }
+    float p = expf(s - lse_bh[i]);
+    ps[i] = p;
+    dss[i] = p * (dp - del_bh[i]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < d; c += 64) {
+    float av = 0.f, ak = 0.f;
+    for (int i = 0; i < N; ++i) {
+      av = fmaf(ps[i], Io<T>::ld(dout, ((size_t)b * N + i) * Dm + h * d + c), av);
+      ak = fmaf(dss[i], Io<T>::ld(base, (size_t)i * D3 + h * d + c) * scale, ak);
+    }
+    Io<T>::st(dqkv, ((size_t)b * N + j) * D3 + Dm + h * d + c, ak);
+    Io<T>::st(dqkv, ((size_t)b * N + j) * D3 + 2 * Dm + h * d + c, av);
+  }
+}
+
+int fc_attn_bwd_generic(int dt, const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int B, int N, int H,
+                        int d, float scale, hipStream_t s) {
+  long rows = (long)B * H * N;
+  int grid = fc_cdiv(rows, 4);
+  size_t shq = (size_t)4 * (2 * d + N) * sizeof(float), shk = (size_t)4 * (2 * d + 2 * N) * sizeof(float);
+  DISPATCH_DT(dt, {
+    hipLaunchKernelGGL(k_attn_delta<T>, dim3(grid), dim3(256), 0, s, (const T*)o, (const T*)dout, delta, B, N, H, d);
+    hipLaunchKernelGGL(k_attn_bwd_q<T>, dim3(grid), dim3(256), shq, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, B, N, H, d, scale);
+    hipLaunchKernelGGL(k_attn_bwd_kv<T>, dim3(grid), dim3(256), shk, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, B, N, H, d, scale);
+  });
+  FC_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,81 @@
+// Host-side launchers of every HIP kernel on the hot path.  All are asynchronous on `stream`,
+// return 0 on success (<0 + fc_last_error() otherwise), and never allocate.
+// dt: element type of activations: FC_F32 (0) or FC_BF16 (1).
+#pragma once
+#include "fc_common.h"
+
+enum { FC_F32 = 0, FC_BF16 = 1 };
+static inline size_t fc_esize(int dt) { return dt == FC_BF16 ? 2 : 4; }
+#define DISPATCH_DT(dt, ...)                 \
+  if ((dt) == FC_F32) { typedef float T; __VA_ARGS__; } \
+  else { typedef bf16_t T; __VA_ARGS__; }
+
+// ---- layer norm (K3)
+int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
+                     int M, int D, float eps, hipStream_t s);
+// dx = (res ? res : 0) + LNbwd(dy); dg/db accumulated (atomics) into fp32 grads
+int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
+                     const void* res, void* dx, float* dg, float* db, int M, int D, hipStream_t s);
+
+// ---- image embedding (K1): patches[B*np, C*P*P] (conv-weight order), cls rows, and backward pieces
+int fc_patchify(int dt, const float* img, void* patches, int B, int C, int HW, int P, hipStream_t s);
+int fc_cls_rows(int dt, const float* cls, const float* pos, void* x, int B, int N, int D, hipStream_t s);
+int fc_img_embed_bwd(int dt, const void* dx, float* dpos, float* dcls, void* dtok, int B, int N, int D, hipStream_t s);
+
+// ---- text embedding (K2): gather + add + LN(eps) ; backward re-gathers
+int fc_txt_embed_fwd(int dt, const int64_t* ids, const float* word, const float* pos, const float* type, const float* g,
+                     const float* b, void* y, float* mean, float* rstd, int B, int N, int D, int vocab, float eps, hipStream_t s);
+int fc_txt_embed_bwd(int dt, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type,
+                     const float* mean, const float* rstd, const float* g, float* dword, float* dpos, float* dtype,
+                     float* dg, float* db, int B, int N, int D, int vocab, hipStream_t s);
+
+// ---- final LN on cls rows + (optional) L2 normalise (K10)
+int fc_head_fwd(int dt, const void* x, const float* g, const float* b, float* f, float* mean, float* rstd, float* nrm,
+                float* out, int B, int N, int D, float eps, int normalize, hipStream_t s);
+// din: d(out) if normalize else d(f); writes dx for ALL rows of [B,N,D] (zeros off the cls rows)
+int fc_head_bwd(int dt, const float* din, const float* out, const float* nrm, int normalize, const void* x,
+                const float* mean, const float* rstd, const float* g, void* dx, float* dg, float* db, int B, int N, int D,
+                hipStream_t s);
+
+// ---- losses (K11, K12).  lossbuf[0] += loss*B (running epoch sum), lossbuf[1] += loss (caller zeroes [1] per step)
+int fc_contrastive_fwd_bwd(const float* a, const float* b, int B, int D, float tau, float* scratch /* 2*B*B+2*B floats */,
+                           float* lossbuf, float* da, float* db, hipStream_t s);
+int fc_ce_fwd_bwd(const float* logits, const int64_t* y, int B, int C, float* lossbuf, float* dlogits, hipStream_t s);
+
+// ---- optimizer (K13): torch.optim.AdamW semantics; optionally refreshes the low-precision shadow and zeroes grads
+int fc_adamw(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd,
+             int step, void* shadow_bf16, int zero_grad, hipStream_t s);
+int fc_cast(int dt_out, const float* src, void* dst, size_t n, hipStream_t s);
+// W_eff = W + s*A (K9) into dst (type dt)
+int fc_reparam_fold(int dt, const float* W, const float* A, const float* scale, void* dst, size_t n, hipStream_t s);
+// given dW_eff in gW: ds += <gW, A>; gA = s*gW (if gA != null)
+int fc_reparam_grad(const float* gW, const float* A, const float* scale, float* ds, float* gA, size_t n, hipStream_t s);
+
+// ---- column sum (bias grads): db[n] (+)= sum_m dy[m,n]
+int fc_colsum(int dt, const void* dy, float* db, int M, int N, int accumulate, hipStream_t s);
+
+// ---- aggregation (K14): out[i] = wg*g[i] + sum_j w[j]*theta_j[i] over a segment table (host-computed weights)
+// seg table on device: for each segment s: offset, numel, then weights  wg, w[0..m)
+int fc_blend_segments(float* out, const float* g, const float* const* thetas /* device array of m ptrs */, int m,
+                      const int64_t* seg_off, const int64_t* seg_len, const float* seg_w /* [nseg, m+1] */, int nseg,
+                      hipStream_t s);
+int fc_scale_segments_impl(float* buf, const int64_t* seg_off, const int64_t* seg_len, const float* seg_w, int nseg, hipStream_t s);
+
+// ---- generic strided GEMM (any shape; fp32 accumulate).  C[m,n] = epi( sum_k A(m,k)*B(k,n) )
+// A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], C row-major with leading dim ldc.
+int fc_gemm_generic(int dtA, int dtB, int dtC, const void* A, long sam, long sak, const void* Bm, long sbk, long sbn,
+                    void* C, long ldc, int M, int N, int K, const GemmEpi& epi, hipStream_t s);
+
+// ---- MFMA bf16 GEMMs (gfx950): returns 1 if the shape is not supported by the fast path (caller falls to generic)
+// kinds: NT: C[M,N] = A[M,K] . W[N,K]^T ; NN: C[M,N] = A[M,K] . W[K,N] ; TN: C[M,N] = A[K,M]^T . B[K,N]
+enum { FC_GEMM_NT = 0, FC_GEMM_NN = 1, FC_GEMM_TN = 2 };
+int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K,
+                 const GemmEpi& epi, hipStream_t s);
+
+// ---- attention (K5).  qkv: [B,N,3,H,d] row-major (= the qkv GEMM output [B*N, 3*H*d]); o: [B,N,H*d]; lse: [B,H,N]
+int fc_attn_fwd_generic(int dt, const void* qkv, void* o, float* lse, int B, int N, int H, int d, float scale, hipStream_t s);
+int fc_attn_bwd_generic(int dt, const void* qkv, const void* o, const void* dout, const float* lse, float* delta,
+                        void* dqkv, int B, int N, int H, int d, float scale, hipStream_t s);
+int fc_attn_fwd_mfma(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H, int d, float scale, hipStream_t s);
+int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv,
+                     int B, int N, int H, int d, float scale, hipStream_t s);

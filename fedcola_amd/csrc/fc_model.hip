@@ -1,0 +1,675 @@
+// Host-side driver of the client step: parameter layout (reference state_dict order), workspace carving, and the
+// forward / backward / step launch sequences.  Everything is enqueued on the caller's stream; nothing allocates.
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/fedcola_hip.h"
+#include "fc_kernels.h"
+
+// ---------------------------------------------------------------- error string
+static thread_local char g_err[1024] = "";
+void fc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* fc_last_error(void) { return g_err; }
+extern "C" int fc_abi_version(void) { return FC_ABI_VERSION; }
+
+// ---------------------------------------------------------------- layout
+struct LinearP {
+  int64_t w = -1, b = -1, scale = -1, aux = -1;
+  int out = 0, in = 0;
+  int seg_w = -1;
+};
+struct BlockP {
+  int64_t n1w, n1b, n2w, n2b;
+  LinearP qkv, proj, fc1, fc2;
+};
+struct TowerP {
+  bool present = false;
+  int64_t pos = -1, cls = -1, pw = -1, pb = -1;                    // img
+  int64_t word = -1, tpos = -1, ttype = -1, lnw = -1, lnb = -1;    // txt
+  std::vector<BlockP> blocks;
+  int64_t head_w = -1, head_b = -1;
+  int task = 0, ncls = 0;
+};
+// memo of the last forward (the autograd engine calls fc_backward from another thread, so this lives in the handle)
+struct LastFwd { const void* ws = nullptr; int B = 0, n_txt = 0, feat_out = 0; const float* droppath = nullptr; const int64_t* ids = nullptr; };
+struct fc_model {
+  mutable LastFwd last;
+  fc_model_cfg cfg;
+  std::vector<fc_segment> segs;
+  int64_t total = 0;
+  TowerP tw[2];
+  int64_t normw = -1, normb = -1;
+  int dt;  // FC_F32 / FC_BF16 activation + compute-weight type
+  bool need_wc;
+  int64_t add(const std::string& name, std::vector<int64_t> shape, int trainable = 1) {
+    fc_segment s;
+    memset(&s, 0, sizeof(s));
+    snprintf(s.name, sizeof(s.name), "%s", name.c_str());
+    s.offset = total;
+    s.numel = 1;
+    s.ndim = (int)shape.size();
+    for (size_t i = 0; i < shape.size(); ++i) { s.shape[i] = shape[i]; s.numel *= shape[i]; }
+    s.trainable = trainable;
+    segs.push_back(s);
+    total += (s.numel + 63) / 64 * 64;
+    return s.offset;
+  }
+};
+
+static void add_linear(fc_model* m, LinearP& L, const std::string& pre, int out, int in, bool reparam, bool aux_trained) {
+  L.out = out; L.in = in;
+  L.seg_w = (int)m->segs.size();
+  L.w = m->add(pre + ".weight", {out, in});
+  L.b = m->add(pre + ".bias", {out});
+  if (reparam) {
+    L.scale = m->add(pre + ".cross_modal_scale", {1});
+    L.aux = m->add(pre + ".aux_weight", {out, in}, aux_trained ? 1 : 0);
+  }
+}
+
+extern "C" int fc_model_create(const fc_model_cfg* c, fc_model_t** out) {
+  FC_REQUIRE(c && out, "fc_model_create: null argument");
+  FC_REQUIRE(c->has_img || c->has_txt, "fc_model_create: no modality");
+  FC_REQUIRE(c->dim > 0 && c->heads > 0 && c->dim % c->heads == 0, "fc_model_create: dim %d not divisible by heads %d", c->dim, c->heads);
+  FC_REQUIRE(c->depth > 0 && c->mlp_hidden > 0, "fc_model_create: bad depth/mlp_hidden");
+  FC_REQUIRE(!(c->aux_attn_only && c->aux_mlp_only), "Both aux_attn_only and aux_mlp_only cannot be True.");  // mome.py:779
+  FC_REQUIRE(c->precision == FC_PREC_FP32 || c->precision == FC_PREC_BF16, "fc_model_create: bad precision");
+  if (c->has_img) FC_REQUIRE(c->img_size % c->patch == 0 && c->in_chans > 0, "fc_model_create: bad image geometry");
+  fc_model* m = new fc_model();
+  m->cfg = *c;
+  m->dt = c->precision == FC_PREC_BF16 ? FC_BF16 : FC_F32;
+  const int D = c->dim;
+  bool uni = !(c->has_img && c->has_txt);
+  bool aux = c->with_aux && uni;                       // mome.py:768
+  bool aux_attn = aux && !c->aux_mlp_only, aux_mlp = aux && !c->aux_attn_only;
+  m->need_wc = (m->dt == FC_BF16) || aux;
+  int present[2] = {c->has_img, c->has_txt};
+  // embeddings first (mome.py:709-723)
+  for (int i = 0; i < 2; ++i) {
+    TowerP& t = m->tw[i];
+    t.present = present[i];
+    if (!t.present) continue;
+    std::string e = "embeddings." + std::to_string(i);
+    if (i == 0) {
+      int np = (c->img_size / c->patch) * (c->img_size / c->patch);
+      t.pos = m->add(e + ".pos_embed", {1, np + 1, D});
+      t.cls = m->add(e + ".cls_token", {1, 1, D});
+      t.pw = m->add(e + ".embed.proj.weight", {D, c->in_chans, c->patch, c->patch});
+      t.pb = m->add(e + ".embed.proj.bias", {D});
+      t.task = c->task_img; t.ncls = c->num_classes_img;
+    } else {
+      e += ".text_embeddings";
+      t.word = m->add(e + ".word_embeddings.weight", {c->vocab, D});
+      t.tpos = m->add(e + ".position_embeddings.weight", {c->max_text_len, D});
+      t.ttype = m->add(e + ".token_type_embeddings.weight", {2, D});
+      t.lnw = m->add(e + ".LayerNorm.weight", {D});
+      t.lnb = m->add(e + ".LayerNorm.bias", {D});
+      t.task = c->task_txt; t.ncls = c->num_classes_txt;
+    }
+  }
+  // blocks (mome.py:729-750)
+  for (int i = 0; i < 2; ++i) {
+    TowerP& t = m->tw[i];
+    if (!t.present) continue;
+    t.blocks.resize(c->depth);
+    for (int l = 0; l < c->depth; ++l) {
+      std::string p = "blockses." + std::to_string(i) + "." + std::to_string(l);
+      BlockP& b = t.blocks[l];
+      b.n1w = m->add(p + ".norm1.weight", {D});
+      b.n1b = m->add(p + ".norm1.bias", {D});
+      add_linear(m, b.qkv, p + ".attn.qkv", 3 * D, D, aux_attn, c->aux_trained);
+      add_linear(m, b.proj, p + ".attn.proj", D, D, aux_attn, c->aux_trained);
+      b.n2w = m->add(p + ".norm2.weight", {D});
+      b.n2b = m->add(p + ".norm2.bias", {D});
+      add_linear(m, b.fc1, p + ".mlp.fc1", c->mlp_hidden, D, aux_mlp, c->aux_trained);
+      add_linear(m, b.fc2, p + ".mlp.fc2", D, c->mlp_hidden, aux_mlp, c->aux_trained);
+    }
+  }
+  m->normw = m->add("norm.weight", {D});
+  m->normb = m->add("norm.bias", {D});
+  for (int i = 0; i < 2; ++i) {
+    TowerP& t = m->tw[i];
+    if (!t.present || t.task != FC_TASK_CLS || t.ncls <= 0) continue;
+    std::string h = "heads." + std::to_string(i) + ".head";
+    t.head_w = m->add(h + ".weight", {t.ncls, D});
+    t.head_b = m->add(h + ".bias", {t.ncls});
+  }
+  *out = m;
+  return 0;
+}
+extern "C" void fc_model_destroy(fc_model_t* m) { delete m; }
+extern "C" int64_t fc_model_num_params(const fc_model_t* m) { return m->total; }
+extern "C" int32_t fc_model_num_segments(const fc_model_t* m) { return (int32_t)m->segs.size(); }
+extern "C" int fc_model_segment(const fc_model_t* m, int32_t i, fc_segment* out) {
+  FC_REQUIRE(i >= 0 && i < (int)m->segs.size(), "fc_model_segment: index %d out of range", i);
+  *out = m->segs[i];
+  return 0;
+}
+extern "C" int fc_model_set_trainable(fc_model_t* m, int32_t seg, int32_t trainable) {
+  FC_REQUIRE(seg >= 0 && seg < (int)m->segs.size(), "fc_model_set_trainable: index %d out of range", seg);
+  m->segs[seg].trainable = trainable;
+  return 0;
+}
+extern "C" size_t fc_compute_weights_bytes(const fc_model_t* m) { return m->need_wc ? (size_t)m->total * fc_esize(m->dt) : 0; }
+
+// ---------------------------------------------------------------- workspace
+struct LayerWs {
+  float *mean1, *rstd1, *mean2, *rstd2, *lse;
+  void *h1, *qkv, *o, *xmid, *h2, *u, *gact;
+};
+struct TowerWs {
+  int M = 0, N = 0;
+  void *patches = nullptr, *dtok = nullptr;
+  float *emb_mean = nullptr, *emb_rstd = nullptr;
+  std::vector<void*> x;
+  std::vector<LayerWs> L;
+  float *f, *hmean, *hrstd, *nrm, *out, *logits, *dlogits, *df;
+};
+struct Ws {
+  TowerWs t[2];
+  void *dxa, *dxb, *dbig, *dqkv, *dh, *dO, *dxs;
+  float *delta, *loss_scratch, *dout[2];
+  int B, n_txt, feat_out;
+  const float* droppath;
+  const int64_t* ids;
+  size_t bytes;
+};
+struct Bump {
+  char* base;
+  size_t off = 0;
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += (bytes + 255) / 256 * 256;
+    return p;
+  }
+};
+struct WsHeader {  // persisted at the start of the workspace so fc_backward knows what the forward did
+  int32_t B, n_txt, feat_out, magic;
+  const float* droppath;
+  const int64_t* ids;
+};
+
+static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
+  const fc_model_cfg& c = m->cfg;
+  Bump bp{(char*)base};
+  bp.take(sizeof(WsHeader));
+  size_t es = fc_esize(m->dt);
+  const int D = c.dim, Hd = c.mlp_hidden;
+  int maxM = 0;
+  for (int i = 0; i < 2; ++i) {
+    TowerWs& t = w.t[i];
+    if (!m->tw[i].present) continue;
+    t.N = i == 0 ? (c.img_size / c.patch) * (c.img_size / c.patch) + 1 : n_txt;
+    t.M = B * t.N;
+    if (t.M > maxM) maxM = t.M;
+    if (i == 0) {
+      size_t kp = (size_t)c.in_chans * c.patch * c.patch;
+      t.patches = bp.take((size_t)B * (t.N - 1) * kp * es);
+      t.dtok = bp.take((size_t)B * (t.N - 1) * D * es);
+    } else {
+      t.emb_mean = (float*)bp.take(sizeof(float) * t.M);
+      t.emb_rstd = (float*)bp.take(sizeof(float) * t.M);
+    }
+    t.x.resize(c.depth + 1);
+    t.L.resize(c.depth);
+    for (int l = 0; l <= c.depth; ++l) t.x[l] = bp.take((size_t)t.M * D * es);
+    for (int l = 0; l < c.depth; ++l) {
+      LayerWs& L = t.L[l];
+      L.mean1 = (float*)bp.take(sizeof(float) * t.M);
+      L.rstd1 = (float*)bp.take(sizeof(float) * t.M);
+      L.mean2 = (float*)bp.take(sizeof(float) * t.M);
+      L.rstd2 = (float*)bp.take(sizeof(float) * t.M);
+      L.lse = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * t.N);
+      L.h1 = bp.take((size_t)t.M * D * es);
+      L.qkv = bp.take((size_t)t.M * 3 * D * es);
+      L.o = bp.take((size_t)t.M * D * es);
+      L.xmid = bp.take((size_t)t.M * D * es);
+      L.h2 = bp.take((size_t)t.M * D * es);
+      L.u = bp.take((size_t)t.M * Hd * es);
+      L.gact = bp.take((size_t)t.M * Hd * es);
+    }
+    int nc = m->tw[i].ncls > 0 ? m->tw[i].ncls : 1;
+    t.f = (float*)bp.take(sizeof(float) * (size_t)B * D);
+    t.hmean = (float*)bp.take(sizeof(float) * B);
+    t.hrstd = (float*)bp.take(sizeof(float) * B);
+    t.nrm = (float*)bp.take(sizeof(float) * B);
+    t.out = (float*)bp.take(sizeof(float) * (size_t)B * D);
+    t.logits = (float*)bp.take(sizeof(float) * (size_t)B * nc);
+    t.dlogits = (float*)bp.take(sizeof(float) * (size_t)B * nc);
+    t.df = (float*)bp.take(sizeof(float) * (size_t)B * D);
+    w.dout[i] = (float*)bp.take(sizeof(float) * (size_t)B * (D > nc ? D : nc));
+  }
+  w.dxa = bp.take((size_t)maxM * D * es);
+  w.dxb = bp.take((size_t)maxM * D * es);
+  w.dxs = bp.take((size_t)maxM * D * es);
+  w.dh = bp.take((size_t)maxM * D * es);
+  w.dO = bp.take((size_t)maxM * D * es);
+  w.dbig = bp.take((size_t)maxM * Hd * es);
+  w.dqkv = bp.take((size_t)maxM * 3 * D * es);
+  int maxN = 0;
+  for (int i = 0; i < 2; ++i) if (m->tw[i].present && w.t[i].N > maxN) maxN = w.t[i].N;
+  w.delta = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * maxN);
+  w.loss_scratch = (float*)bp.take(sizeof(float) * (2 * (size_t)B * B + 2 * B + 64));
+  w.bytes = bp.off;
+  w.B = B; w.n_txt = n_txt;
+}
+
+extern "C" size_t fc_workspace_bytes(const fc_model_t* m, int32_t B, int32_t n_txt) {
+  Ws w;
+  carve(m, B, n_txt, nullptr, w);
+  return w.bytes;
+}
+extern "C" size_t fc_contrastive_scratch_floats(int32_t B) { return 2 * (size_t)B * B + 2 * (size_t)B + 64; }
+
+// ---------------------------------------------------------------- weights
+template <typename F>
+static int for_each_linear(const fc_model* m, F f) {
+  for (int i = 0; i < 2; ++i) {
+    if (!m->tw[i].present) continue;
+    for (const BlockP& b : m->tw[i].blocks) {
+      FC_TRY(f(b.qkv)); FC_TRY(f(b.proj)); FC_TRY(f(b.fc1)); FC_TRY(f(b.fc2));
+    }
+  }
+  return 0;
+}
+
+extern "C" int fc_prepare_weights(const fc_model_t* m, const float* params, void* wc, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!m->need_wc) return 0;
+  FC_REQUIRE(wc && wc != (const void*)params, "fc_prepare_weights: a separate compute-weight buffer is required");
+  FC_TRY(fc_cast(m->dt, params, wc, (size_t)m->total, s));
+  size_t es = fc_esize(m->dt);
+  return for_each_linear(m, [&](const LinearP& L) -> int {
+    if (L.aux < 0) return 0;
+    return fc_reparam_fold(m->dt, params + L.w, params + L.aux, params + L.scale, (char*)wc + (size_t)L.w * es, (size_t)L.out * L.in, s);
+  });
+}
+
+extern "C" int fc_upload_fold(const fc_model_t* m, const float* params, float* dst, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (dst != params) FC_CHECK_HIP(hipMemcpyAsync(dst, params, sizeof(float) * (size_t)m->total, hipMemcpyDeviceToDevice, s));
+  return for_each_linear(m, [&](const LinearP& L) -> int {
+    if (L.aux < 0) return 0;
+    return fc_reparam_fold(FC_F32, params + L.w, params + L.aux, params + L.scale, dst + L.w, (size_t)L.out * L.in, s);
+  });
+}
+
+// ---------------------------------------------------------------- GEMM dispatch (MFMA fast path when available)
+struct Ctx {
+  const fc_model* m;
+  const float* params;
+  const char* wc;  // compute weights (type m->dt), same element offsets as params
+  hipStream_t s;
+  int dt;
+  size_t es;
+  const void* W(int64_t off) const { return wc + (size_t)off * es; }
+  // Y[M,N] = X[M,K] . W[N,K]^T
+  int gemm_fwd(const void* X, const void* Wt, void* Y, int M, int N, int K, const GemmEpi& e) const {
+    if (dt == FC_BF16) {
+      int r = fc_gemm_mfma(FC_GEMM_NT, FC_BF16, (const bf16_t*)X, K, (const bf16_t*)Wt, K, Y, N, M, N, K, e, s);
+      if (r <= 0) return r;
+    }
+    return fc_gemm_generic(dt, dt, dt, X, K, 1, Wt, 1, K, Y, N, M, N, K, e, s);
+  }
+  // dX[M,K] = dY[M,N] . W[N,K]
+  int gemm_dx(const void* dY, const void* Wt, void* dX, int M, int N, int K, const GemmEpi& e) const {
+    if (dt == FC_BF16) {
+      int r = fc_gemm_mfma(FC_GEMM_NN, FC_BF16, (const bf16_t*)dY, N, (const bf16_t*)Wt, K, dX, K, M, K, N, e, s);
+      if (r <= 0) return r;
+    }
+    return fc_gemm_generic(dt, dt, dt, dY, N, 1, Wt, K, 1, dX, K, M, K, N, e, s);
+  }
+  // dW[N,K] = dY[M,N]^T . X[M,K]   (fp32 out)
+  int gemm_dw(const void* dY, const void* X, float* dW, int M, int N, int K) const {
+    GemmEpi e;
+    if (dt == FC_BF16) {
+      int r = fc_gemm_mfma(FC_GEMM_TN, FC_F32, (const bf16_t*)dY, N, (const bf16_t*)X, K, dW, K, N, K, M, e, s);
+      if (r <= 0) return r;
+    }
+    return fc_gemm_generic(dt, dt, FC_F32, dY, 1, N, X, K, 1, dW, K, N, K, M, e, s);
+  }
+  int attn_fwd(const void* qkv, void* o, float* lse, int B, int N) const {
+    int H = m->cfg.heads, d = m->cfg.dim / H;
+    float scale = 1.0f / sqrtf((float)d);
+    if (dt == FC_BF16) {
+      int r = fc_attn_fwd_mfma((const bf16_t*)qkv, (bf16_t*)o, lse, B, N, H, d, scale, s);
+      if (r <= 0) return r;
+    }
+    return fc_attn_fwd_generic(dt, qkv, o, lse, B, N, H, d, scale, s);
+  }
+  int attn_bwd(const void* qkv, const void* o, const void* dO, const float* lse, float* delta, void* dqkv, int B, int N) const {
+    int H = m->cfg.heads, d = m->cfg.dim / H;
+    float scale = 1.0f / sqrtf((float)d);
+    if (dt == FC_BF16) {
+      int r = fc_attn_bwd_mfma((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dO, lse, delta, (bf16_t*)dqkv, B, N, H, d, scale, s);
+      if (r <= 0) return r;
+    }
+    return fc_attn_bwd_generic(dt, qkv, o, dO, lse, delta, dqkv, B, N, H, d, scale, s);
+  }
+};
+
+// scaled copy for drop-path backward: dst[m,:] = src[m,:] * rowscale[m / rows_per_sample]
+template <typename T>
+__global__ void __launch_bounds__(256) k_rowscale(const T* __restrict__ src, T* __restrict__ dst, const float* __restrict__ rs, int rows_per_sample,
+                                                  size_t n, int D) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    Io<T>::st(dst, i, Io<T>::ld(src, i) * rs[(i / D) / rows_per_sample]);
+}
+static int rowscale(int dt, const void* src, void* dst, const float* rs, int rows_per_sample, int M, int D, hipStream_t s) {
+  size_t n = (size_t)M * D;
+  int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (dt == FC_F32) hipLaunchKernelGGL(k_rowscale<float>, dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, rs, rows_per_sample, n, D);
+  else hipLaunchKernelGGL(k_rowscale<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, rs, rows_per_sample, n, D);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+static const float* dp_ptr(const fc_model* m, const float* droppath, int tower, int layer, int branch, int B) {
+  if (!droppath) return nullptr;
+  return droppath + (((size_t)tower * m->cfg.depth + layer) * 2 + branch) * B;
+}
+
+// ---------------------------------------------------------------- forward (mome.py:881-922)
+static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int64_t* ids, int feat_out, float* out) {
+  const fc_model* m = c.m;
+  const fc_model_cfg& cf = m->cfg;
+  const TowerP& tp = m->tw[i];
+  TowerWs& t = w.t[i];
+  const int D = cf.dim, B = w.B, N = t.N, M = t.M, Hd = cf.mlp_hidden;
+  const float* P = c.params;
+  if (i == 0) {  // ImageEmbedding.forward mome.py:597-611
+    int np = N - 1, kp = cf.in_chans * cf.patch * cf.patch;
+    FC_TRY(fc_patchify(c.dt, img, t.patches, B, cf.in_chans, cf.img_size, cf.patch, c.s));
+    GemmEpi e;
+    e.bias = P + tp.pb;
+    e.patch_rows = np;
+    e.pos = P + tp.pos;
+    FC_TRY(c.gemm_fwd(t.patches, c.W(tp.pw), t.x[0], B * np, D, kp, e));
+    FC_TRY(fc_cls_rows(c.dt, P + tp.cls, P + tp.pos, t.x[0], B, N, D, c.s));
+  } else {  // TextEmbedding.forward mome.py:632-639
+    FC_REQUIRE(N <= cf.max_text_len, "text length %d exceeds max_text_len %d", N, cf.max_text_len);
+    FC_TRY(fc_txt_embed_fwd(c.dt, ids, P + tp.word, P + tp.tpos, P + tp.ttype, P + tp.lnw, P + tp.lnb, t.x[0], t.emb_mean, t.emb_rstd, B, N, D,
+                            cf.vocab, 1e-12f, c.s));
+  }
+  for (int l = 0; l < cf.depth; ++l) {  // Block.forward mome.py:225-228
+    const BlockP& b = tp.blocks[l];
+    LayerWs& L = t.L[l];
+    FC_TRY(fc_layernorm_fwd(c.dt, t.x[l], P + b.n1w, P + b.n1b, L.h1, L.mean1, L.rstd1, M, D, 1e-5f, c.s));
+    { GemmEpi e; e.bias = P + b.qkv.b; FC_TRY(c.gemm_fwd(L.h1, c.W(b.qkv.w), L.qkv, M, 3 * D, D, e)); }
+    FC_TRY(c.attn_fwd(L.qkv, L.o, L.lse, B, N));
+    { GemmEpi e; e.bias = P + b.proj.b; e.res = t.x[l]; e.rowscale = dp_ptr(m, w.droppath, i, l, 0, B); e.rows_per_sample = N;
+      FC_TRY(c.gemm_fwd(L.o, c.W(b.proj.w), L.xmid, M, D, D, e)); }
+    FC_TRY(fc_layernorm_fwd(c.dt, L.xmid, P + b.n2w, P + b.n2b, L.h2, L.mean2, L.rstd2, M, D, 1e-5f, c.s));
+    { GemmEpi e; e.bias = P + b.fc1.b; e.preact = L.u; FC_TRY(c.gemm_fwd(L.h2, c.W(b.fc1.w), L.gact, M, Hd, D, e)); }
+    { GemmEpi e; e.bias = P + b.fc2.b; e.res = L.xmid; e.rowscale = dp_ptr(m, w.droppath, i, l, 1, B); e.rows_per_sample = N;
+      FC_TRY(c.gemm_fwd(L.gact, c.W(b.fc2.w), t.x[l + 1], M, D, Hd, e)); }
+  }
+  int normalize = feat_out || tp.task == FC_TASK_RTV;
+  FC_TRY(fc_head_fwd(c.dt, t.x[cf.depth], P + m->normw, P + m->normb, t.f, t.hmean, t.hrstd, t.nrm, t.out, B, N, D, 1e-6f, normalize, c.s));
+  if (normalize) {
+    if (out) FC_CHECK_HIP(hipMemcpyAsync(out, t.out, sizeof(float) * (size_t)B * D, hipMemcpyDeviceToDevice, c.s));
+  } else {
+    FC_REQUIRE(tp.task == FC_TASK_CLS && tp.head_w >= 0, "tower %d has no head for feat_out=0", i);
+    GemmEpi e;
+    e.bias = P + tp.head_b;
+    FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, t.f, D, 1, P + tp.head_w, 1, D, t.logits, tp.ncls, B, tp.ncls, D, e, c.s));
+    if (out) FC_CHECK_HIP(hipMemcpyAsync(out, t.logits, sizeof(float) * (size_t)B * tp.ncls, hipMemcpyDeviceToDevice, c.s));
+  }
+  return 0;
+}
+
+static int check_ws(const fc_model* m, int B, int n_txt, void* workspace, size_t bytes, Ws& w) {
+  FC_REQUIRE(B > 0, "batch must be positive");
+  FC_REQUIRE(workspace != nullptr, "workspace is null");
+  carve(m, B, n_txt, workspace, w);
+  FC_REQUIRE(w.bytes <= bytes, "workspace too small: need %zu bytes, got %zu", w.bytes, bytes);
+  return 0;
+}
+
+static int forward_impl(const fc_model* m, const float* params, const void* wc, const float* img, const int64_t* ids, int B, int n_txt,
+                        int feat_out, const float* droppath, void* workspace, size_t wbytes, float* out_img, float* out_txt, hipStream_t s, Ws& w) {
+  FC_REQUIRE(params, "params is null");
+  if (m->need_wc) FC_REQUIRE(wc && wc != (const void*)params, "this configuration needs a compute-weight buffer (fc_prepare_weights)");
+  // 'None modality should have None input.' (mome.py:890)
+  FC_REQUIRE(m->tw[0].present == (img != nullptr), "None modality should have None input. (img)");
+  FC_REQUIRE(m->tw[1].present == (ids != nullptr), "None modality should have None input. (txt)");
+  FC_TRY(check_ws(m, B, m->tw[1].present ? n_txt : 0, workspace, wbytes, w));
+  w.feat_out = feat_out; w.droppath = droppath; w.ids = ids;
+  Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
+  if (m->tw[0].present) FC_TRY(tower_forward(c, w, 0, img, nullptr, feat_out, out_img));
+  if (m->tw[1].present) FC_TRY(tower_forward(c, w, 1, nullptr, ids, feat_out, out_txt));
+  return 0;
+}
+
+
+extern "C" int fc_forward(const fc_model_t* m, const float* params, const void* wc, const float* img, const int64_t* ids, int32_t B,
+                          int32_t n_txt, int32_t feat_out, const float* droppath, void* workspace, size_t workspace_bytes, float* out_img,
+                          float* out_txt, void* stream) {
+  Ws w;
+  FC_TRY(forward_impl(m, params, wc, img, ids, B, n_txt, feat_out, droppath, workspace, workspace_bytes, out_img, out_txt, (hipStream_t)stream, w));
+  m->last = LastFwd{workspace, B, w.n_txt, feat_out, droppath, ids};
+  return 0;
+}
+
+// ---------------------------------------------------------------- backward
+static int linear_bwd_params(const Ctx& c, const LinearP& L, const void* dY, const void* X, int M, float* grads) {
+  FC_TRY(c.gemm_dw(dY, X, grads + L.w, M, L.out, L.in));
+  FC_TRY(fc_colsum(c.dt, dY, grads + L.b, M, L.out, 1, c.s));
+  return 0;
+}
+
+static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float* grads) {
+  const fc_model* m = c.m;
+  const fc_model_cfg& cf = m->cfg;
+  const TowerP& tp = m->tw[i];
+  TowerWs& t = w.t[i];
+  const int D = cf.dim, B = w.B, N = t.N, M = t.M, Hd = cf.mlp_hidden;
+  const float* P = c.params;
+  int normalize = w.feat_out || tp.task == FC_TASK_RTV;
+  const float* din = d_out;
+  if (!normalize) {  // ClassificationHead backward (mome.py:647-649)
+    GemmEpi e;
+    FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, d_out, tp.ncls, 1, P + tp.head_w, D, 1, t.df, D, B, D, tp.ncls, e, c.s));      // df = dlogits . Wh
+    GemmEpi ea; ea.accumulate = 1;
+    FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, d_out, 1, tp.ncls, t.f, D, 1, grads + tp.head_w, D, tp.ncls, D, B, ea, c.s));   // dWh = dlogits^T f
+    FC_TRY(fc_colsum(FC_F32, d_out, grads + tp.head_b, B, tp.ncls, 1, c.s));
+    din = t.df;
+  }
+  void* dx = w.dxa;
+  void* dx2 = w.dxb;
+  FC_TRY(fc_head_bwd(c.dt, din, t.out, t.nrm, normalize, t.x[cf.depth], t.hmean, t.hrstd, P + m->normw, dx, grads + m->normw, grads + m->normb, B, N,
+                     D, c.s));
+  for (int l = cf.depth - 1; l >= 0; --l) {
+    const BlockP& b = tp.blocks[l];
+    LayerWs& L = t.L[l];
+    // ---- MLP branch: x_{l+1} = xmid + s2 * (gact.W2^T + b2)
+    const float* s2 = dp_ptr(m, w.droppath, i, l, 1, B);
+    const void* dm = dx;
+    if (s2) { FC_TRY(rowscale(c.dt, dx, w.dxs, s2, N, M, D, c.s)); dm = w.dxs; }
+    FC_TRY(linear_bwd_params(c, b.fc2, dm, L.gact, M, grads));
+    { GemmEpi e; e.gelu_in = L.u; FC_TRY(c.gemm_dx(dm, c.W(b.fc2.w), w.dbig, M, D, Hd, e)); }                 // du = (dm.W2) * gelu'(u)
+    FC_TRY(linear_bwd_params(c, b.fc1, w.dbig, L.h2, M, grads));
+    { GemmEpi e; FC_TRY(c.gemm_dx(w.dbig, c.W(b.fc1.w), w.dh, M, Hd, D, e)); }                                 // dh2
+    FC_TRY(fc_layernorm_bwd(c.dt, w.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, dx, dx2, grads + b.n2w, grads + b.n2b, M, D, c.s));  // dxmid
+    // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp)
+    const float* s1 = dp_ptr(m, w.droppath, i, l, 0, B);
+    const void* da = dx2;
+    if (s1) { FC_TRY(rowscale(c.dt, dx2, w.dxs, s1, N, M, D, c.s)); da = w.dxs; }
+    FC_TRY(linear_bwd_params(c, b.proj, da, L.o, M, grads));
+    { GemmEpi e; FC_TRY(c.gemm_dx(da, c.W(b.proj.w), w.dO, M, D, D, e)); }
+    FC_TRY(c.attn_bwd(L.qkv, L.o, w.dO, L.lse, w.delta, w.dqkv, B, N));
+    FC_TRY(linear_bwd_params(c, b.qkv, w.dqkv, L.h1, M, grads));
+    { GemmEpi e; FC_TRY(c.gemm_dx(w.dqkv, c.W(b.qkv.w), w.dh, M, 3 * D, D, e)); }                               // dh1
+    FC_TRY(fc_layernorm_bwd(c.dt, w.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, dx2, dx, grads + b.n1w, grads + b.n1b, M, D, c.s));  // dx_l
+  }
+  if (i == 0) {
+    int np = N - 1, kp = cf.in_chans * cf.patch * cf.patch;
+    FC_TRY(fc_img_embed_bwd(c.dt, dx, grads + tp.pos, grads + tp.cls, t.dtok, B, N, D, c.s));
+    FC_TRY(c.gemm_dw(t.dtok, t.patches, grads + tp.pw, B * np, D, kp));
+    FC_TRY(fc_colsum(c.dt, t.dtok, grads + tp.pb, B * np, D, 1, c.s));
+  } else {
+    FC_TRY(fc_txt_embed_bwd(c.dt, dx, w.ids, P + tp.word, P + tp.tpos, P + tp.ttype, t.emb_mean, t.emb_rstd, P + tp.lnw, grads + tp.word,
+                            grads + tp.tpos, grads + tp.ttype, grads + tp.lnw, grads + tp.lnb, B, N, D, cf.vocab, c.s));
+  }
+  // CrossModalReparamLinear: route dW_eff (mome.py:58-60)
+  for (const BlockP& b : tp.blocks) {
+    const LinearP* Ls[4] = {&b.qkv, &b.proj, &b.fc1, &b.fc2};
+    for (const LinearP* L : Ls) {
+      if (L->aux < 0) continue;
+      float* gA = m->segs[L->seg_w + 3].trainable ? grads + L->aux : nullptr;
+      FC_TRY(fc_reparam_grad(grads + L->w, P + L->aux, P + L->scale, grads + L->scale, gA, (size_t)L->out * L->in, c.s));
+    }
+  }
+  return 0;
+}
+
+static int backward_impl(const fc_model* m, const float* params, const void* wc, const float* d_out_img, const float* d_out_txt, float* grads,
+                         Ws& w, hipStream_t s) {
+  Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
+  if (m->tw[0].present && d_out_img) FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
+  if (m->tw[1].present && d_out_txt) FC_TRY(tower_backward(c, w, 1, d_out_txt, grads));
+  return 0;
+}
+
+extern "C" int fc_backward(const fc_model_t* m, const float* params, const void* wc, const float* d_out_img, const float* d_out_txt,
+                           float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+  FC_REQUIRE(m->last.ws == workspace && workspace, "fc_backward: no matching fc_forward on this workspace precedes this call");
+  Ws w;
+  FC_TRY(check_ws(m, m->last.B, m->last.n_txt, workspace, workspace_bytes, w));
+  w.feat_out = m->last.feat_out; w.droppath = m->last.droppath; w.ids = m->last.ids;
+  return backward_impl(m, params, wc, d_out_img, d_out_txt, grads, w, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- losses / optimizer / step
+extern "C" int fc_contrastive_loss_fwd_bwd(const float* a, const float* b, int32_t B, int32_t D, float tau, float* scratch, size_t scratch_floats,
+                                           float* lossbuf, float* da, float* db, void* stream) {
+  FC_REQUIRE(scratch_floats >= fc_contrastive_scratch_floats(B), "contrastive: scratch too small");
+  return fc_contrastive_fwd_bwd(a, b, B, D, tau, scratch, lossbuf, da, db, (hipStream_t)stream);
+}
+extern "C" int fc_ce_loss_fwd_bwd(const float* logits, const int64_t* y, int32_t B, int32_t C, float* lossbuf, float* dlogits, void* stream) {
+  return fc_ce_fwd_bwd(logits, y, B, C, lossbuf, dlogits, (hipStream_t)stream);
+}
+
+static int adamw_ranges(const fc_model* m, float* p, float* g, float* mm, float* vv, float lr, float b1, float b2, float eps, float wd, int step,
+                        hipStream_t s) {
+  // contiguous runs of trainable segments (padding included) -> one launch each; frozen segments are skipped like torch
+  size_t i = 0, n = m->segs.size();
+  while (i < n) {
+    if (!m->segs[i].trainable) { ++i; continue; }
+    size_t j = i;
+    while (j + 1 < n && m->segs[j + 1].trainable) ++j;
+    int64_t beg = m->segs[i].offset;
+    int64_t end = (j + 1 < n) ? m->segs[j + 1].offset : m->total;
+    FC_TRY(fc_adamw(p + beg, g + beg, mm + beg, vv + beg, (size_t)(end - beg), lr, b1, b2, eps, wd, step, nullptr, 0, s));
+    i = j + 1;
+  }
+  return 0;
+}
+extern "C" int fc_adamw_step(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  FC_REQUIRE(step >= 1, "adamw: step is 1-based");
+  return adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+}
+
+// exp(clamp(log(1/0.07), 0, log 100)) evaluated in fp32 like the upstream nn.Parameter (a fresh criterion is built
+// every step at fedavgclient.py:95, so the temperature never trains)
+static float contrastive_tau() { return expf(fminf(fmaxf(logf(1.0f / 0.07f), 0.0f), logf(100.0f))); }
+
+extern "C" int fc_client_step(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
+                              const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  FC_REQUIRE(grads && exp_avg && exp_avg_sq && lossbuf, "fc_client_step: null buffer");
+  FC_REQUIRE(step >= 1, "fc_client_step: step is 1-based");
+  bool both = m->tw[0].present && m->tw[1].present;
+  if (!both) FC_REQUIRE(labels != nullptr, "fc_client_step: uni-modal clients need labels");
+  Ws w;
+  FC_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->total, s));   // optimizer.zero_grad() fedavgclient.py:79
+  FC_CHECK_HIP(hipMemsetAsync(lossbuf + 1, 0, sizeof(float), s));
+  FC_TRY(forward_impl(m, params, wc, img, ids, B, n_txt, both ? 1 : 0, droppath, workspace, workspace_bytes, nullptr, nullptr, s, w));
+  m->last = LastFwd{workspace, B, w.n_txt, both ? 1 : 0, droppath, ids};
+  const float *d0 = nullptr, *d1 = nullptr;
+  if (both) {  // fedavgclient.py:91-95
+    FC_TRY(fc_contrastive_fwd_bwd(w.t[0].out, w.t[1].out, B, m->cfg.dim, contrastive_tau(), w.loss_scratch, lossbuf, w.dout[0], w.dout[1], s));
+    d0 = w.dout[0]; d1 = w.dout[1];
+  } else {     // fedavgclient.py:81-90
+    int i = m->tw[0].present ? 0 : 1;
+    FC_REQUIRE(m->tw[i].task == FC_TASK_CLS, "fc_client_step: uni-modal tower must be a 'cls' task");
+    FC_TRY(fc_ce_fwd_bwd(w.t[i].logits, labels, B, m->tw[i].ncls, lossbuf, w.dout[i], s));
+    (i == 0 ? d0 : d1) = w.dout[i];
+  }
+  FC_TRY(backward_impl(m, params, wc, d0, d1, grads, w, s));
+  FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s));
+  if (m->need_wc) FC_TRY(fc_prepare_weights(m, params, wc, stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------- aggregation
+extern "C" int fc_aggregate_blend(float* out, const float* global, const float* const* thetas, int32_t n_clients, const int64_t* seg_offset,
+                                  const int64_t* seg_numel, const float* seg_weights, int32_t n_segments, void* stream) {
+  return fc_blend_segments(out, global, thetas, n_clients, seg_offset, seg_numel, seg_weights, n_segments, (hipStream_t)stream);
+}
+extern "C" int fc_scale_segments(float* buf, const int64_t* seg_offset, const int64_t* seg_numel, const float* seg_weight, int32_t n_segments,
+                                 void* stream) {
+  return fc_scale_segments_impl(buf, seg_offset, seg_numel, seg_weight, n_segments, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- kernel-level test entry points
+extern "C" int fc_k_layernorm_fwd(int32_t dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int32_t M,
+                                  int32_t D, float eps, void* stream) {
+  return fc_layernorm_fwd(dt, x, g, b, y, mean, rstd, M, D, eps, (hipStream_t)stream);
+}
+extern "C" int fc_k_layernorm_bwd(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res,
+                                  void* dx, float* dg, float* db, int32_t M, int32_t D, void* stream) {
+  return fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, (hipStream_t)stream);
+}
+extern "C" int fc_k_gemm(int32_t impl, int32_t kind, int32_t dt_in, int32_t dt_out, const void* A, const void* Bm, void* C, int32_t M, int32_t N,
+                         int32_t K, const float* bias, int32_t gelu, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GemmEpi e;
+  e.bias = bias;
+  FC_REQUIRE(!gelu, "fc_k_gemm: gelu epilogue is exercised through fc_forward");
+  if (impl == 1) {
+    FC_REQUIRE(dt_in == FC_BF16, "fc_k_gemm: MFMA path takes bf16 inputs");
+    long lda = kind == FC_GEMM_TN ? M : K, ldb = kind == FC_GEMM_NT ? K : N;
+    return fc_gemm_mfma(kind, dt_out, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, C, N, M, N, K, e, s);
+  }
+  long sam, sak, sbk, sbn;
+  if (kind == FC_GEMM_NT) { sam = K; sak = 1; sbk = 1; sbn = K; }
+  else if (kind == FC_GEMM_NN) { sam = K; sak = 1; sbk = N; sbn = 1; }
+  else { sam = 1; sak = M; sbk = N; sbn = 1; }
+  return fc_gemm_generic(dt_in, dt_in, dt_out, A, sam, sak, Bm, sbk, sbn, C, N, M, N, K, e, s);
+}
+extern "C" int fc_k_attention_fwd(int32_t impl, int32_t dt, const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, int32_t d,
+                                  float scale, void* stream) {
+  if (impl == 1) {
+    FC_REQUIRE(dt == FC_BF16, "MFMA attention takes bf16");
+    return fc_attn_fwd_mfma((const bf16_t*)qkv, (bf16_t*)o, lse, B, N, H, d, scale, (hipStream_t)stream);
+  }
+  return fc_attn_fwd_generic(dt, qkv, o, lse, B, N, H, d, scale, (hipStream_t)stream);
+}
+extern "C" int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, const void* o, const void* dout, const float* lse, float* delta,
+                                  void* dqkv, int32_t B, int32_t N, int32_t H, int32_t d, float scale, void* stream) {
+  if (impl == 1) {
+    FC_REQUIRE(dt == FC_BF16, "MFMA attention takes bf16");
+    return fc_attn_bwd_mfma((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, B, N, H, d, scale,
+                            (hipStream_t)stream);
+  }
+  return fc_attn_bwd_generic(dt, qkv, o, dout, lse, delta, dqkv, B, N, H, d, scale, (hipStream_t)stream);
+}
+extern "C" int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd, int32_t step,
+                          void* stream) {
+  return fc_adamw(p, g, m, v, (size_t)n, lr, beta1, beta2, eps, wd, step, nullptr, 0, (hipStream_t)stream);
+}
+extern "C" int fc_k_cast(int32_t dt_out, const float* src, void* dst, int64_t n, void* stream) {
+  return fc_cast(dt_out, src, dst, (size_t)n, (hipStream_t)stream);
+}

@@ -1,0 +1,135 @@
+/* fedcola_hip.h -- C ABI of the MI355X-native FedCola client-step library (libfedcola_hip.so).
+ *
+ * Drop-in boundary for the reference's per-client local training step.  The reference has no FFI (it is pure
+ * Python/PyTorch); each entry point below names the reference code it replaces so a maintainer can bind it from
+ * src/models/mome.py / src/client/fedavgclient.py / src/server/fedavgserver.py with ctypes.
+ *
+ * Conventions: plain pointers and sizes only; every data pointer is a DEVICE pointer owned by the caller; all
+ * work is enqueued asynchronously on the caller's hipStream_t (passed as void*); no hidden allocation, no host
+ * synchronisation; return 0 on success, <0 on error (message: fc_last_error()).  A handle is not thread-safe:
+ * use one per device/stream.
+ */
+#ifndef FEDCOLA_HIP_H
+#define FEDCOLA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FC_ABI_VERSION 1
+
+enum { FC_PREC_FP32 = 0, FC_PREC_BF16 = 1 };
+enum { FC_TASK_NONE = 0, FC_TASK_CLS = 1, FC_TASK_RTV = 2 };
+
+/* Mirrors ModalityAgnosticTransformer.__init__ (src/models/mome.py:672-769) + factories (mome.py:924-1033). */
+typedef struct fc_model_cfg {
+  int32_t has_img, has_txt;             /* modalities = ['img'|None, 'txt'|None] */
+  int32_t img_size, patch, in_chans;
+  int32_t dim, depth, heads, mlp_hidden;
+  int32_t vocab, max_text_len;
+  int32_t task_img, task_txt;           /* FC_TASK_* per tower (tasks=[...]) */
+  int32_t num_classes_img, num_classes_txt;
+  int32_t with_aux, aux_trained, aux_attn_only, aux_mlp_only; /* CrossModalReparamLinear, mome.py:42-97,771-786 */
+  int32_t precision;                    /* FC_PREC_*: storage type of activations / compute weights */
+} fc_model_cfg;
+
+typedef struct fc_model fc_model_t;
+
+/* One state_dict entry of the reference model inside the flat fp32 parameter buffer. */
+typedef struct fc_segment {
+  char name[128];       /* exact reference state_dict key, e.g. "blockses.0.3.attn.qkv.weight" */
+  int64_t offset;       /* in floats from the start of the flat buffer (64-element aligned) */
+  int64_t numel;
+  int32_t ndim;
+  int64_t shape[4];
+  int32_t trainable;    /* requires_grad (aux_weight: only when aux_trained) */
+} fc_segment;
+
+const char* fc_last_error(void);
+int fc_abi_version(void);
+
+/* ---- model handle: layout only, owns no device memory (mome.py:672-769) */
+int fc_model_create(const fc_model_cfg* cfg, fc_model_t** out);
+void fc_model_destroy(fc_model_t* m);
+int64_t fc_model_num_params(const fc_model_t* m);        /* padded flat length in floats */
+int32_t fc_model_num_segments(const fc_model_t* m);
+int fc_model_segment(const fc_model_t* m, int32_t i, fc_segment* out);
+int fc_model_set_trainable(fc_model_t* m, int32_t seg, int32_t trainable);  /* fedavgserver.py:422-429 freeze */
+
+/* ---- sizes of caller-provided buffers */
+size_t fc_workspace_bytes(const fc_model_t* m, int32_t B, int32_t n_txt);   /* activations saved for backward + temporaries */
+size_t fc_compute_weights_bytes(const fc_model_t* m);                        /* 0 => pass the params buffer itself */
+
+/* compute weights = cast(params) with W_eff = W + s*A folded in (mome.py:58-60). Call after params change. */
+int fc_prepare_weights(const fc_model_t* m, const float* params, void* wc, void* stream);
+
+/* ---- ModalityAgnosticTransformer.forward(x=[img|None, txt|None], feat_out) (mome.py:881-922)
+ * img: float32 [B,3,H,W] (1-channel handled by the caller, mome.py:893-894); ids: int64 [B,n_txt].
+ * out_img/out_txt: float32 [B, dim] (feat_out or 'rtv': unit-norm features) or [B, num_classes] ('cls' logits).
+ * droppath: NULL (eval / rate 0) or float32 [2][depth][2][B] multipliers (0 or 1/keep) -- timm DropPath (mome.py:213,223).
+ * Saves activations for fc_backward in `workspace`. */
+int fc_forward(const fc_model_t* m, const float* params, const void* wc, const float* img, const int64_t* ids,
+               int32_t B, int32_t n_txt, int32_t feat_out, const float* droppath, void* workspace, size_t workspace_bytes,
+               float* out_img, float* out_txt, void* stream);
+
+/* Backward of the last fc_forward on this workspace: loss.backward() (fedavgclient.py:97).
+ * d_out_*: float32 gradients w.r.t. the forward outputs (NULL for an absent tower).
+ * grads: flat float32 buffer laid out like params; must be zero-filled by the caller (gradients accumulate). */
+int fc_backward(const fc_model_t* m, const float* params, const void* wc, const float* d_out_img, const float* d_out_txt,
+                float* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- criteria.  lossbuf: float32[2] device; lossbuf[0] += loss*B (MetricManager.track, src/utils.py:337-343),
+ * lossbuf[1] += loss (zero it before the call to read this step's loss). */
+/* torchmultimodal ContrastiveLossWithTemperature as used at fedavgclient.py:95 (tau fixed) */
+int fc_contrastive_loss_fwd_bwd(const float* a, const float* b, int32_t B, int32_t D, float tau, float* scratch,
+                                size_t scratch_floats, float* lossbuf, float* da, float* db, void* stream);
+size_t fc_contrastive_scratch_floats(int32_t B);
+/* nn.CrossEntropyLoss() (fedavgclient.py:85,90) */
+int fc_ce_loss_fwd_bwd(const float* logits, const int64_t* y, int32_t B, int32_t C, float* lossbuf, float* dlogits, void* stream);
+
+/* ---- torch.optim.AdamW.step over the trainable ranges of the flat buffers (fedavgclient.py:63,100). step is 1-based. */
+int fc_adamw_step(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* ---- one iteration of FedavgClient.update's batch loop (fedavgclient.py:79-102), fully on device:
+ * zero_grad -> forward -> criterion -> backward -> AdamW.step -> refresh compute weights.
+ * labels: int64 [B] for 'cls' towers (uni-modal clients), NULL for img+txt retrieval (contrastive loss). */
+int fc_client_step(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc,
+                   const float* img, const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt,
+                   const float* droppath, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                   float* lossbuf, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- FedavgServer._aggregate blend (fedavgserver.py:656-664) in closed form:
+ * out[seg] = w[seg][0]*global[seg] + sum_j w[seg][1+j]*thetas[j][seg].  All arrays are device memory. */
+int fc_aggregate_blend(float* out, const float* global, const float* const* thetas, int32_t n_clients,
+                       const int64_t* seg_offset, const int64_t* seg_numel, const float* seg_weights, int32_t n_segments,
+                       void* stream);
+/* in-place per-segment scaling (pre-weighting before an RCCL all-reduce(sum)) */
+int fc_scale_segments(float* buf, const int64_t* seg_offset, const int64_t* seg_numel, const float* seg_weight,
+                      int32_t n_segments, void* stream);
+/* FedavgClient.upload aux fold (fedavgclient.py:173-181): dst[weight] = W + A*s for every re-param linear, rest copied */
+int fc_upload_fold(const fc_model_t* m, const float* params, float* dst, void* stream);
+
+/* ---- individual kernels exposed for unit tests / reuse (dt: 0 = f32, 1 = bf16) */
+int fc_k_layernorm_fwd(int32_t dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
+                       int32_t M, int32_t D, float eps, void* stream);
+int fc_k_layernorm_bwd(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
+                       const void* res, void* dx, float* dg, float* db, int32_t M, int32_t D, void* stream);
+/* kind: 0 NT (C=A.W^T, A[M,K], W[N,K]); 1 NN (C=A.W, A[M,K], W[K,N]); 2 TN (C=A^T.B, A[K,M], B[K,N]).
+ * impl: 0 generic VALU, 1 MFMA bf16 (returns 1 when the shape is unsupported). dtC: type of C. bias may be NULL. */
+int fc_k_gemm(int32_t impl, int32_t kind, int32_t dt_in, int32_t dt_out, const void* A, const void* B, void* C, int32_t M,
+              int32_t N, int32_t K, const float* bias, int32_t gelu, void* stream);
+/* impl: 0 generic, 1 MFMA flash (bf16, d=64) */
+int fc_k_attention_fwd(int32_t impl, int32_t dt, const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H,
+                       int32_t d, float scale, void* stream);
+int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, const void* o, const void* dout, const float* lse,
+                       float* delta, void* dqkv, int32_t B, int32_t N, int32_t H, int32_t d, float scale, void* stream);
+int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+               int32_t step, void* stream);
+int fc_k_cast(int32_t dt_out, const float* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,175 @@
+"""Kernel-level parity on the GPU: each HIP kernel (called through the C ABI) against the oracle's formulas."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from oracle import mome_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def L():
+    from fedcola_amd import _lib
+    return _lib
+
+
+_KEEP = []
+
+
+def dev(t, dt=None):
+    """Device copy that stays alive until the end of the test (raw pointers are handed to the C ABI)."""
+    t = t.cuda()
+    t = t.to(dt) if dt is not None else t
+    _KEEP.append(t)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return t
+
+
+def maxerr(a, b):
+    return float((a.detach().double().cpu() - b.double()).abs().max())
+
+
+def amax(b):
+    return max(1.0, float(b.abs().max()))
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+DT = {"fp32": (0, torch.float32, 2e-5), "bf16": (1, torch.bfloat16, 2e-2)}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,D", [(5, 4), (37, 192), (300, 384), (64, 1024)])
+def test_layernorm(prec, M, D):
+    code, tdt, tol = DT[prec]
+    g = torch.Generator().manual_seed(M * 1000 + D)
+    x = torch.randn(M, D, generator=g).to(tdt).float()
+    dy = torch.randn(M, D, generator=g).to(tdt).float()
+    res = torch.randn(M, D, generator=g).to(tdt).float()
+    gam = torch.randn(D, generator=g) * 0.2 + 1
+    bet = torch.randn(D, generator=g) * 0.1
+    y_ref, saved = O.ln_fwd(x, gam, bet, 1e-5)
+    dx_ref, dg_ref, db_ref = O.ln_bwd(dy, gam, saved)
+    xd, dyd, resd = dev(x, tdt), dev(dy, tdt), dev(res, tdt)
+    y = torch.empty_like(xd); dx = torch.empty_like(xd)
+    mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
+    dg = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
+    lib = L().lib()
+    L().check(lib.fc_k_layernorm_fwd(code, P(xd), P(dev(gam)), P(dev(bet)), P(y), P(mean), P(rstd), M, D, 1e-5, S()))
+    L().check(lib.fc_k_layernorm_bwd(code, P(dyd), P(xd), P(mean), P(rstd), P(dev(gam)), P(resd), P(dx), P(dg), P(db), M, D, S()))
+    torch.cuda.synchronize()
+    e = maxerr(y, y_ref); assert e <= tol * amax(y_ref), f"y err {e}"
+    e = maxerr(dx, dx_ref + res); assert e <= tol * amax(dx_ref + res), f"dx err {e}"
+    e = maxerr(dg, dg_ref); assert e <= 1e-4 * amax(dg_ref), f"dg err {e}"
+    e = maxerr(db, db_ref); assert e <= 1e-4 * amax(db_ref), f"db err {e}"
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(5, 7, 3), (70, 130, 33), (197 * 4, 384, 384), (256, 1152, 384), (394, 384, 1536), (1000, 192, 768)])
+def test_gemm(impl, kind, prec, M, N, K):
+    if impl == 1 and prec == "fp32":
+        pytest.skip("MFMA path is bf16")
+    code, tdt, tol = DT[prec]
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + kind)
+    shpA = (M, K) if kind != 2 else (K, M)
+    shpB = (N, K) if kind == 0 else (K, N)
+    A = (torch.randn(*shpA, generator=g) * 0.5).to(tdt)
+    Bm = (torch.randn(*shpB, generator=g) * 0.5).to(tdt)
+    bias = torch.randn(N, generator=g)
+    a = A.float() if kind != 2 else A.float().t()
+    b = Bm.float().t() if kind == 0 else Bm.float()
+    ref = a.double() @ b.double() + bias.double()
+    for out_code, out_dt in ((code, tdt), (0, torch.float32)):
+        Cd = torch.zeros(M, N, device="cuda", dtype=out_dt)
+        rc = L().lib().fc_k_gemm(impl, kind, code, out_code, P(dev(A)), P(dev(Bm)), P(Cd), M, N, K, P(dev(bias)), 0, S())
+        if rc == 1:
+            pytest.skip("shape not covered by the MFMA fast path")
+        L().check(rc)
+        torch.cuda.synchronize()
+        err = (Cd.double().cpu() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        t = 1e-5 if (prec == "fp32") else (1e-2 if out_dt == torch.bfloat16 else 2e-5 * math.sqrt(K) + 1e-6)
+        assert err <= t * max(1.0, scale), (err, scale, out_dt)
+
+
+def attn_ref(qkv, B, N, H, d):
+    q5 = qkv.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4).double()
+    q, k, v = q5[0] * d ** -0.5, q5[1], q5[2]
+    S_ = q @ k.transpose(-2, -1)
+    Pm = torch.softmax(S_, -1)
+    o = (Pm @ v).transpose(1, 2).reshape(B, N, H * d)
+    lse = torch.logsumexp(S_, -1)
+    return q, k, v, Pm, o, lse
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,N,H,d", [(2, 5, 2, 2), (3, 197, 3, 64), (2, 32, 6, 64), (2, 16, 1, 64), (1, 40, 2, 32), (2, 70, 2, 64)])
+def test_attention(impl, prec, B, N, H, d):
+    if impl == 1 and prec == "fp32":
+        pytest.skip("MFMA path is bf16")
+    code, tdt, tol = DT[prec]
+    g = torch.Generator().manual_seed(B * 100 + N)
+    D = H * d
+    qkv = (torch.randn(B, N, 3 * D, generator=g) * 1.0).to(tdt)
+    dout = (torch.randn(B, N, D, generator=g) * 0.5).to(tdt)
+    q, k, v, Pm, o_ref, lse_ref = attn_ref(qkv.float(), B, N, H, d)
+    qd = dev(qkv); o = torch.zeros(B, N, D, device="cuda", dtype=tdt)
+    lse = torch.zeros(B, H, N, device="cuda")
+    scale = d ** -0.5
+    rc = L().lib().fc_k_attention_fwd(impl, code, P(qd), P(o), P(lse), B, N, H, d, scale, S())
+    if rc == 1:
+        pytest.skip("shape not covered by the MFMA fast path")
+    L().check(rc)
+    torch.cuda.synchronize()
+    t = 2e-5 if prec == "fp32" else 2e-2
+    e = maxerr(o, o_ref); assert e <= t * amax(o_ref), f"o err {e}"
+    e = maxerr(lse, lse_ref); assert e <= (1e-4 if prec == "fp32" else 2e-2), f"lse err {e}"
+    # backward (uses the device's own o / lse)
+    dO4 = dout.double().reshape(B, N, H, d).transpose(1, 2)
+    dV = Pm.transpose(-2, -1) @ dO4
+    dP = dO4 @ v.transpose(-2, -1)
+    dS = Pm * (dP - (dP * Pm).sum(-1, keepdim=True))
+    dq = (dS @ k) * scale
+    dk = dS.transpose(-2, -1) @ q
+    dref = torch.stack([dq, dk, dV], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * D)
+    dqkv = torch.zeros(B, N, 3 * D, device="cuda", dtype=tdt)
+    delta = torch.zeros(B, H, N, device="cuda")
+    L().check(L().lib().fc_k_attention_bwd(impl, code, P(qd), P(o), P(dev(dout)), P(lse), P(delta), P(dqkv), B, N, H, d, scale, S()))
+    torch.cuda.synchronize()
+    err = (dqkv.double().cpu() - dref).abs().max().item()
+    assert err <= (5e-5 if prec == "fp32" else 3e-2) * max(1, dref.abs().max().item()), err
+
+
+def test_adamw_matches_oracle():
+    n = 4096 + 64
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g) * 1e-3
+    m = torch.zeros(n); v = torch.zeros(n)
+    pd, gd, md, vd = dev(p.clone()), dev(gr.clone()), dev(m.clone()), dev(v.clone())
+    for step in (1, 2, 3):
+        O.adamw_step(p, gr, m, v, step, 1e-3, weight_decay=0.01)
+        L().check(L().lib().fc_k_adamw(P(pd), P(gd), P(md), P(vd), n, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, S()))
+    torch.cuda.synchronize()
+    assert maxerr(pd, p) <= 2e-6, maxerr(pd, p)
+    assert maxerr(md, m) <= 1e-9 and maxerr(vd, v) <= 1e-12
+
+
+def test_cast_bf16_rne():
+    x = torch.randn(1000) * 3
+    y = torch.empty(1000, device="cuda", dtype=torch.bfloat16)
+    L().check(L().lib().fc_k_cast(1, P(dev(x)), P(y), 1000, S()))
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), x.to(torch.bfloat16))

@@ -1,0 +1,121 @@
+"""Model-level parity on the GPU: the HIP client step (through the C ABI) against the oracle and the golden vectors."""
+import pytest
+import torch
+
+import golden_util as G
+import product_util as PU
+from oracle import mome_oracle as O
+from test_oracle_golden import cfg_from_mk
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["toy", "small", "imgcls_aux", "txtcls_aux"]
+
+
+def grad_tol(k, go, grads_o, weights, rtol, atol):
+    """Tolerance for one gradient tensor.  cross_modal_scale's gradient is the scalar <dW_eff, A>: a sum with heavy
+    cancellation, so its error bound scales with sum|dW_eff*A|, not with the (small) result."""
+    if k.endswith("cross_modal_scale"):
+        wk = k.replace("cross_modal_scale", "weight")
+        ak = k.replace("cross_modal_scale", "aux_weight")
+        return rtol * float((grads_o[wk] * weights[ak]).abs().sum()) + atol
+    return rtol * max(float(go.abs().max()), 1e-6) + atol
+
+
+def oracle_step(case, rec, dp_masks=None):
+    cfg = cfg_from_mk(rec["mk"])
+    p = G.case_weights(case)
+    img, ids, y = G.case_inputs(rec)
+    batch = {"img+txt": ("img+txt", img, ids), "img": ("img", img, y), "txt": ("txt", ids, y)}[rec["kind"]]
+    state = dict(step=0, m={}, v={})
+    loss, outs, grads = O.client_step(p, cfg, batch, state, lr=rec["lr"], dp_masks=dp_masks)
+    return cfg, p, float(loss), outs, grads
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_client_step_fp32_vs_oracle_and_golden(case):
+    rec = G.load(f"model_{case}.json")
+    cfg, p_after, loss_o, outs_o, grads_o = oracle_step(case, rec)
+    img, ids, y = G.case_inputs(rec)
+    model = PU.build_product(rec["mk"], "fp32", G.case_weights(case))
+    # forward outputs (autograd-free path)
+    model.train()
+    with torch.no_grad():
+        outs = model([img.cuda() if rec["kind"] != "txt" else None, ids.cuda() if rec["kind"] != "img" else None],
+                     feat_out=rec["kind"] == "img+txt")
+    for o, oo, r in zip(outs, outs_o, rec["outs"]):
+        if oo is None:
+            assert o is None
+            continue
+        assert (o.cpu() - oo).abs().max() <= 1e-4 * max(1.0, float(oo.abs().max())), "outs vs oracle"
+        G.compare(o, r, 1e-4, 1e-6, f"{case} outs vs golden")
+    loss, grads, st = PU.product_step(model, rec["kind"], img, ids, y, rec["lr"])
+    assert abs(loss - loss_o) <= 1e-4 * max(1.0, abs(loss_o))
+    assert abs(loss - rec["loss"]) <= 1e-4 * max(1.0, abs(rec["loss"]))
+    w0 = G.case_weights(case)
+    for k, go in grads_o.items():
+        err = float((grads[k] - go).abs().max())
+        assert err <= grad_tol(k, go, grads_o, w0, 1e-4, 1e-7), f"grad {k}: err {err} scale {float(go.abs().max())}"
+        if rec["grads"][k] is not None and not k.endswith("cross_modal_scale"):
+            G.compare(grads[k], rec["grads"][k], 3e-4, 1e-7, f"{case} grad {k} vs golden")
+    sd = model.state_dict()
+    for k, r in rec["after"].items():
+        G.compare_after_adamw(sd[k], r, rec["grads"][k], rec["lr"], f"{case} after {k}")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_client_step_bf16_close_to_oracle(case):
+    """bf16 storage / MFMA mode: stated tolerance 6e-2 of each gradient tensor's max (bf16 has 8 mantissa bits and
+    errors compound over depth); loss within 3e-2."""
+    rec = G.load(f"model_{case}.json")
+    cfg, p_after, loss_o, outs_o, grads_o = oracle_step(case, rec)
+    img, ids, y = G.case_inputs(rec)
+    model = PU.build_product(rec["mk"], "bf16", G.case_weights(case))
+    model.train()
+    loss, grads, st = PU.product_step(model, rec["kind"], img, ids, y, rec["lr"])
+    assert abs(loss - loss_o) <= 3e-2 * max(1.0, abs(loss_o))
+    w0 = G.case_weights(case)
+    for k, go in grads_o.items():
+        err = float((grads[k] - go).abs().max())
+        assert err <= grad_tol(k, go, grads_o, w0, 6e-2, 1e-6), f"bf16 grad {k}: err {err} scale {float(go.abs().max())}"
+
+
+def test_autograd_path_and_droppath_masks():
+    """loss.backward() through the autograd.Function, with explicit DropPath multipliers, vs the oracle."""
+    case = "small"
+    rec = G.load(f"model_{case}.json")
+    img, ids, y = G.case_inputs(rec)
+    B = rec["B"]
+    depth = rec["mk"]["depth"]
+    dp = torch.ones(2, depth, 2, B)
+    dp[0, 1, 0] = torch.tensor([2.0, 0.0, 2.0, 0.0]); dp[0, 1, 1] = torch.tensor([0.0, 2.0, 2.0, 0.0])
+    dp[1, 0, 1] = torch.tensor([1.25, 1.25, 0.0, 1.25]); dp[1, 1, 0] = torch.tensor([0.0, 0.0, 2.0, 2.0])
+    masks = {(t, l, br): dp[t, l, br] for t in range(2) for l in range(depth) for br in range(2)}
+    cfg, p_after, loss_o, outs_o, grads_o = oracle_step(case, rec, dp_masks=masks)
+    model = PU.build_product(rec["mk"], "fp32", G.case_weights(case))
+    model.train()
+    outs = model([img.cuda(), ids.cuda()], feat_out=True, droppath=dp.cuda().contiguous())
+    tau = O.contrastive_tau()
+    Lg = tau * outs[0] @ outs[1].t()
+    lab = torch.arange(B, device="cuda")
+    loss = 0.5 * (torch.nn.functional.cross_entropy(Lg, lab) + torch.nn.functional.cross_entropy(Lg.t(), lab))
+    loss.backward()
+    assert abs(float(loss) - loss_o) <= 1e-4
+    named = dict(model.named_parameters())
+    for k, go in grads_o.items():
+        scale = max(float(go.abs().max()), 1e-6)
+        err = float((named[k].grad.cpu() - go).abs().max())
+        assert err <= 1e-4 * scale + 1e-7, f"grad {k}: err {err} scale {scale}"
+
+
+def test_errors_are_loud():
+    from fedcola_amd._lib import FedcolaHipError
+    rec = G.load("model_imgcls_aux.json")
+    model = PU.build_product(rec["mk"], "fp32", G.case_weights("imgcls_aux"))
+    with pytest.raises(AssertionError):
+        model([None, torch.zeros(2, 8, dtype=torch.long).cuda()])        # None modality should have None input
+    with pytest.raises(AssertionError):
+        model([torch.zeros(2, 3, 32, 32).cuda(), None])                  # image size mismatch
+    cpu_model = PU.build_product(rec["mk"], "fp32", G.case_weights("imgcls_aux")).cpu()
+    with pytest.raises(FedcolaHipError):
+        cpu_model([torch.zeros(2, 3, 224, 224), None])                   # no CPU fallback
