@@ -1,0 +1,309 @@
+// bf16 MFMA attention for gfx950, head_dim 64, whole key range resident (N <= 256: ViT tokens 197, captions <= 64).
+// Reference semantics: Attention.forward, /root/reference/src/models/mome.py:150-168 (scores and softmax in fp32).
+//
+// One workgroup (4 waves) per (batch, head).  K and V (and, for the backward, Q and dO) tiles [Npad][64] bf16 sit in
+// LDS as 128-B rows with ONE swizzle that serves both read forms without bank conflicts (chunk c of row r at
+// c ^ hd(r), hd below): row reads (ds_read_b128, MFMA operands that are k-contiguous) and transposed 4x16 block reads
+// (ds_read_b64_tr_b16, operands whose k index is the tile's row).
+//
+// Every product is arranged so that an accumulator tile feeds the next MFMA as an operand with no lane movement:
+//   fwd : S^T = K.Q^T (rows = keys, cols = queries) -> softmax down the rows (in-lane + 2 shuffles) -> O^T = V^T.P^T
+//   bwd1: S^T, dP^T = V.dO^T -> dS^T -> dQ = (dS^T)^T.K            (waves split the query blocks)
+//   bwd2: S = Q.K^T, dP = dO.V^T -> P, dS -> dV = P^T.dO, dK = dS^T.Q   (waves split the key blocks; no atomics)
+// P is recomputed from the forward's log-sum-exp; nothing of size N x N ever goes to HBM.
+#include "fc_kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define LDS3(p) ((__attribute__((address_space(3))) s16x4*)(p))
+
+__device__ __forceinline__ int hd(int row) {
+  int t = (row >> 1) & 7;
+  return ((((t >> 1) ^ (t >> 2)) & 1) << 2) | ((t & 1) << 1) | (t >> 2);
+}
+__device__ __forceinline__ int at_off(int row, int c) { return row * 128 + ((c ^ hd(row)) << 4); }
+
+// row read: lane (r = lane&15, g = lane>>4) gets T[rb + r][32*ks + 8g .. +7]
+__device__ __forceinline__ bf16x8 row_frag(const char* T, int rb, int ks, int lane) {
+  return *(const bf16x8*)(T + at_off(rb + (lane & 15), ks * 4 + (lane >> 4)));
+}
+// transposed read for a 32-row k-step starting at row r0: lane (c = lane&15, g) gets
+//   { T[r0 + 4g + j][cb + c] (j = 0..3), T[r0 + 16 + 4g + j][cb + c] (j = 0..3) }
+__device__ __forceinline__ bf16x8 tr_frag(const char* T, int r0, int cb, int lane) {
+  int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  int col = cb + 4 * p, c = col >> 3, cbyte = (col & 7) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS3(T + at_off(r0 + 4 * g + q, c) + cbyte));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS3(T + at_off(r0 + 16 + 4 * g + q, c) + cbyte));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 f;
+  f[0] = (short)f2bf(a[0]); f[1] = (short)f2bf(a[1]); f[2] = (short)f2bf(a[2]); f[3] = (short)f2bf(a[3]);
+  f[4] = (short)f2bf(b[0]); f[5] = (short)f2bf(b[1]); f[6] = (short)f2bf(b[2]); f[7] = (short)f2bf(b[3]);
+  return f;
+}
+// stage a [N][64] slice (row stride ld elements) into a swizzled LDS tile of npad rows (zero rows past N)
+__device__ __forceinline__ void stage_tile(char* T, const bf16_t* __restrict__ src, long ld, int N, int npad, int tid) {
+  for (int idx = tid; idx < npad * 8; idx += 256) {
+    int row = idx >> 3, c = idx & 7;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < N) v = *(const uint4*)(src + (size_t)row * ld + c * 8);
+    *(uint4*)(T + at_off(row, c)) = v;
+  }
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// ======================================================================== forward
+template <int NF>  // key fragments of 16 (Npad = 16*NF, NF even)
+__global__ void __launch_bounds__(256) k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse, int B, int N,
+                                                       int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = 16 * NF;
+  char* Ks = smem;
+  char* Vs = smem + NP * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long D3 = 3L * H * 64, Dm = (long)H * 64;
+  const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
+  stage_tile(Ks, base + Dm, D3, N, NP, tid);
+  stage_tile(Vs, base + 2 * Dm, D3, N, NP, tid);
+  __syncthreads();
+  const int nqb = (N + 15) >> 4;
+  for (int qb = wave; qb < nqb; qb += 4) {
+    const int qrow = qb * 16 + cl;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (qrow < N) v = *(const uint4*)(base + (size_t)qrow * D3 + ks * 32 + g * 8);
+      qf[ks] = *(bf16x8*)&v;
+    }
+    f32x4 s[NF];
+    float m = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a = MFMA(row_frag(Ks, f * 16, ks, lane), qf[ks], a);   // S^T[key = 16f+4g+x][q = cl]
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        float v = (f * 16 + 4 * g + x < N) ? a[x] * scale : -INFINITY;
+        a[x] = v;
+        m = fmaxf(m, v);
+      }
+      s[f] = a;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { float p = __expf(s[f][x] - m); s[f][x] = p; sum += p; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    f32x4 oacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ss = 0; ss < NF / 2; ++ss) {
+      bf16x8 pb = pack8(s[2 * ss], s[2 * ss + 1]);                      // P^T[key(8g+j)][q = cl]
+#pragma unroll
+      for (int db = 0; db < 4; ++db) oacc[db] = MFMA(tr_frag(Vs, 32 * ss, db * 16, lane), pb, oacc[db]);   // O^T[d = 16db+4g+x][q]
+    }
+    if (qrow < N) {
+      float inv = 1.0f / sum;
+      bf16_t* orow = o + ((size_t)b * N + qrow) * Dm + h * 64 + 4 * g;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        ushort4 pk;
+        pk.x = f2bf(oacc[db][0] * inv); pk.y = f2bf(oacc[db][1] * inv); pk.z = f2bf(oacc[db][2] * inv); pk.w = f2bf(oacc[db][3] * inv);
+        *(ushort4*)(orow + db * 16) = pk;
+      }
+      if (g == 0) lse[((size_t)b * H + h) * N + qrow] = m + __logf(sum);
+    }
+  }
+}
+
+// ======================================================================== backward
+template <int NF>
+__global__ void __launch_bounds__(256, 1) k_attn_bwd_mfma(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = 16 * NF;
+  char* Qs = smem;
+  char* Ks = Qs + NP * 128;
+  char* Vs = Ks + NP * 128;
+  char* Ds = Vs + NP * 128;
+  float* lse_s = (float*)(Ds + NP * 128);
+  float* del_s = lse_s + NP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long D3 = 3L * H * 64, Dm = (long)H * 64;
+  const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
+  stage_tile(Qs, base, D3, N, NP, tid);
+  stage_tile(Ks, base + Dm, D3, N, NP, tid);
+  stage_tile(Vs, base + 2 * Dm, D3, N, NP, tid);
+  stage_tile(Ds, dout + (size_t)b * N * Dm + h * 64, Dm, N, NP, tid);
+  for (int i = tid; i < NP; i += 256) {
+    lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] : 1e30f;     // padded queries: P = exp(. - 1e30) = 0
+    del_s[i] = i < N ? delta[((size_t)b * H + h) * N + i] : 0.f;
+  }
+  __syncthreads();
+  bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
+  const int nqb = (N + 15) >> 4;
+  // ---------------- phase 1: dQ.  tiles S^T / dP^T (rows = keys, cols = queries)
+  for (int qb = wave; qb < nqb; qb += 4) {
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { qf[ks] = row_frag(Qs, qb * 16, ks, lane); dof[ks] = row_frag(Ds, qb * 16, ks, lane); }
+    const float lq = lse_s[qb * 16 + cl], dq_ = del_s[qb * 16 + cl];
+    f32x4 dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ss = 0; ss < NF / 2; ++ss) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int f = 2 * ss + hh;
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          st = MFMA(row_frag(Ks, f * 16, ks, lane), qf[ks], st);        // S^T[key][q]
+          dpt = MFMA(row_frag(Vs, f * 16, ks, lane), dof[ks], dpt);     // dP^T[key][q] = sum_d V[key][d] dO[q][d]
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ds[hh][x] = __expf(st[x] * scale - lq) * (dpt[x] - dq_);
+      }
+      bf16x8 af = pack8(ds[0], ds[1]);                                  // A[row = q][k = key(8g+j)]
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dq[db] = MFMA(af, tr_frag(Ks, 32 * ss, db * 16, lane), dq[db]);   // dQ[q = 4g+x][d = 16db+cl]
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      int row = qb * 16 + 4 * g + x;
+      if (row < N) {
+        bf16_t* p = dbase + (size_t)row * D3 + cl;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) p[db * 16] = f2bf(dq[db][x] * scale);
+      }
+    }
+  }
+  // ---------------- phase 2: dK, dV.  tiles S / dP (rows = queries, cols = keys)
+  for (int f = wave; f < NF; f += 4) {
+    if (f * 16 >= N) break;
+    bf16x8 kfb[2], vfb[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { kfb[ks] = row_frag(Ks, f * 16, ks, lane); vfb[ks] = row_frag(Vs, f * 16, ks, lane); }
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dv[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int qp = 0; qp < NF / 2; ++qp) {
+      f32x4 P[2], dS[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int qb = 2 * qp + hh;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          sa = MFMA(row_frag(Qs, qb * 16, ks, lane), kfb[ks], sa);      // S[q = 4g+x][key = cl]
+          dpa = MFMA(row_frag(Ds, qb * 16, ks, lane), vfb[ks], dpa);    // dP[q][key] = sum_d dO[q][d] V[key][d]
+        }
+        const float4 l4 = *(const float4*)(lse_s + qb * 16 + 4 * g), d4 = *(const float4*)(del_s + qb * 16 + 4 * g);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          float p = __expf(sa[x] * scale - lv[x]);
+          P[hh][x] = p;
+          dS[hh][x] = p * (dpa[x] - dl[x]);
+        }
+      }
+      bf16x8 pa = pack8(P[0], P[1]), dsa = pack8(dS[0], dS[1]);          // A[row = key = cl][k = q(8g+j)]
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        dv[db] = MFMA(pa, tr_frag(Ds, 32 * qp, db * 16, lane), dv[db]);  // dV[key = 4g+x][d = 16db+cl]
+        dk[db] = MFMA(dsa, tr_frag(Qs, 32 * qp, db * 16, lane), dk[db]); // dK[key][d]
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      int row = f * 16 + 4 * g + x;
+      if (row < N) {
+        bf16_t* pk = dbase + (size_t)row * D3 + Dm + cl;
+        bf16_t* pv = dbase + (size_t)row * D3 + 2 * Dm + cl;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) { pk[db * 16] = f2bf(dk[db][x] * scale); pv[db * 16] = f2bf(dv[db][x]); }
+      }
+    }
+  }
+}
+
+// ======================================================================== launchers
+static int pick_nf(int N) { return N <= 32 ? 2 : N <= 64 ? 4 : N <= 224 ? 14 : N <= 256 ? 16 : 0; }
+
+template <int NF>
+static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
+  const int lds = 2 * 16 * NF * 128;
+  auto k = k_attn_fwd_mfma<NF>;
+  static bool done = false;
+  if (!done) { FC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); done = true; }
+  hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, s, qkv, o, lse, B, N, H, scale);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+template <int NF>
+static int launch_bwd(const bf16_t* qkv, const bf16_t* dout, const float* lse, const float* delta, bf16_t* dqkv, int B, int N, int H, float scale,
+                      hipStream_t s) {
+  const int lds = 4 * 16 * NF * 128 + 2 * 16 * NF * 4;
+  auto k = k_attn_bwd_mfma<NF>;
+  static bool done = false;
+  if (!done) { FC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); done = true; }
+  hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, s, qkv, dout, lse, delta, dqkv, B, N, H, scale);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+int fc_attn_fwd_mfma(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H, int d, float scale, hipStream_t s) {
+  if (d != 64 || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 7)) return 1;
+  switch (pick_nf(N)) {
+    case 2: return launch_fwd<2>(qkv, o, lse, B, N, H, scale, s);
+    case 4: return launch_fwd<4>(qkv, o, lse, B, N, H, scale, s);
+    case 14: return launch_fwd<14>(qkv, o, lse, B, N, H, scale, s);
+    case 16: return launch_fwd<16>(qkv, o, lse, B, N, H, scale, s);
+  }
+  return 1;
+}
+
+// delta[b,h,q] = sum_d dO[q,d] O[q,d]  (one wave per row; 64 lanes = 64 head dims)
+__global__ void __launch_bounds__(256) k_attn_delta64(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta, int B, int N,
+                                                      int H) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= (long)B * H * N) return;
+  int i = (int)(row % N), h = (int)((row / N) % H), b = (int)(row / ((long)N * H));
+  size_t off = ((size_t)b * N + i) * (H * 64) + h * 64 + lane;
+  float s = wave_sum(bf2f(o[off]) * bf2f(dout[off]));
+  if (lane == 0) delta[row] = s;
+}
+
+int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv, int B, int N, int H,
+                     int d, float scale, hipStream_t s) {
+  if (d != 64 || ((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15)) return 1;
+  int nf = pick_nf(N);
+  if (!nf) return 1;
+  hipLaunchKernelGGL(k_attn_delta64, dim3(fc_cdiv((long)B * H * N, 4)), dim3(256), 0, s, o, dout, delta, B, N, H);
+  FC_LAUNCH_CHECK();
+  switch (nf) {
+    case 2: return launch_bwd<2>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
+    case 4: return launch_bwd<4>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
+    case 14: return launch_bwd<14>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
+    case 16: return launch_bwd<16>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
+  }
+  return 1;
+}

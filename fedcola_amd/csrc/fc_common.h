@@ -86,6 +86,7 @@ struct GemmEpi {
   void* preact = nullptr;           // if set: store (acc+bias) here (output type) and write gelu(acc+bias) to C
   const void* gelu_in = nullptr;    // if set: C = acc * gelu'(gelu_in[m,n])   (output type)
   int accumulate = 0;               // C += result (fp32 C only)
+  int out_zeroed = 0;               // caller guarantees C is zero-filled (split-K kernels skip their own memset)
   float alpha = 1.0f;               // result = alpha*acc (+bias...)
   int patch_rows = 0;               // >0: patch-embed remap: out row = m + m/patch_rows + 1, adds pos[1 + m%patch_rows]
   const float* pos = nullptr;       // [1+patch_rows, N] fp32

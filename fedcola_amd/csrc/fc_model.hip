@@ -330,6 +330,7 @@ struct Ctx {
   // dW[N,K] = dY[M,N]^T . X[M,K]   (fp32 out)
   int gemm_dw(const void* dY, const void* X, float* dW, int M, int N, int K) const {
     GemmEpi e;
+    e.out_zeroed = 1;  // the flat gradient buffer is zero-filled before every backward
     if (dt == FC_BF16) {
       int r = fc_gemm_mfma(FC_GEMM_TN, FC_F32, (const bf16_t*)dY, N, (const bf16_t*)X, K, dW, K, N, K, M, e, s);
       if (r <= 0) return r;
