@@ -24,9 +24,159 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const T* __restrict__ x, const f
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+
+// ---- 16-byte vector forms (D % 8 == 0, D <= 1024): a lane owns chunks of 8 consecutive columns; one pass over HBM
+template <typename T> struct V8;
+template <> struct V8<float> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
+    float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[8]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct V8<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+    uint4 u = *(const uint4*)p;
+    const bf16_t* h = (const bf16_t*)&u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = bf2f(h[i]);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+    uint4 u;
+    bf16_t* h = (bf16_t*)&u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = f2bf(v[i]);
+    *(uint4*)p = u;
+  }
+};
+#define LNV_MAXC 2  // chunks of 8 per lane: D <= 64*8*2
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_ln_fwd_v(const T* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                  T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nc = D >> 3;
+  float v[LNV_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < LNV_MAXC; ++t) {
+    int c = lane + 64 * t;
+    if (c < nc) {
+      V8<T>::ld(x + (size_t)row * D + c * 8, v[t]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[t][i];
+    }
+  }
+  float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < LNV_MAXC; ++t)
+    if (lane + 64 * t < nc) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { float d = v[t][i] - mu; q += d * d; }
+    }
+  float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int t = 0; t < LNV_MAXC; ++t) {
+    int c = lane + 64 * t;
+    if (c < nc) {
+      float gg[8], bb[8], o[8];
+      V8<float>::ld(g + c * 8, gg);
+      V8<float>::ld(b + c * 8, bb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (v[t][i] - mu) * rs * gg[i] + bb[i];
+      V8<T>::st(y + (size_t)row * D + c * 8, o);
+    }
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ g, const T* res, T* dx,
+                                                  float* __restrict__ dg, float* __restrict__ db, int M, int D, int rows_per_block) {
+  __shared__ float red[2][4][1024];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nc = D >> 3;
+  float ag[LNV_MAXC][8], ab[LNV_MAXC][8], gg[LNV_MAXC][8];
+#pragma unroll
+  for (int t = 0; t < LNV_MAXC; ++t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ag[t][i] = 0.f; ab[t][i] = 0.f; gg[t][i] = 0.f; }
+    if (lane + 64 * t < nc) V8<float>::ld(g + (lane + 64 * t) * 8, gg[t]);
+  }
+  int row0 = blockIdx.x * rows_per_block;
+  for (int r = wave; r < rows_per_block; r += 4) {
+    int row = row0 + r;
+    if (row >= M) break;
+    float mu = mean[row], rs = rstd[row];
+    float d[LNV_MAXC][8], xh[LNV_MAXC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < LNV_MAXC; ++t) {
+      int c = lane + 64 * t;
+      if (c < nc) {
+        V8<T>::ld(dy + (size_t)row * D + c * 8, d[t]);
+        V8<T>::ld(x + (size_t)row * D + c * 8, xh[t]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          xh[t][i] = (xh[t][i] - mu) * rs;
+          float dxh = d[t][i] * gg[t][i];
+          s1 += dxh; s2 += dxh * xh[t][i];
+          ag[t][i] += d[t][i] * xh[t][i]; ab[t][i] += d[t][i];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int t = 0; t < LNV_MAXC; ++t) {
+      int c = lane + 64 * t;
+      if (c < nc) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rs * (d[t][i] * gg[t][i] - s1 - xh[t][i] * s2);
+        if (res) {
+          float rr[8];
+          V8<T>::ld(res + (size_t)row * D + c * 8, rr);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += rr[i];
+        }
+        V8<T>::st(dx + (size_t)row * D + c * 8, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < LNV_MAXC; ++t) {
+    int c = lane + 64 * t;
+    if (c < nc) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { red[0][wave][c * 8 + i] = ag[t][i]; red[1][wave][c * 8 + i] = ab[t][i]; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) {
+    atomicAdd(dg + i, red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
+    atomicAdd(db + i, red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+  }
+}
+
+static bool ln_vec_ok(const void* a, const void* b, const void* c, const void* d, int D) {
+  return (D % 8 == 0) && D <= 64 * 8 * LNV_MAXC && !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15);
+}
+
 int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int D,
                      float eps, hipStream_t s) {
   if (M <= 0) return 0;
+  if (ln_vec_ok(x, y, g, b, D)) {
+    DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_fwd_v<T>, dim3(fc_cdiv(M, 4)), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, M, D, eps));
+    FC_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_fwd<T>, dim3(fc_cdiv(M, 4)), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, M, D, eps));
   FC_LAUNCH_CHECK();
   return 0;
@@ -93,6 +243,13 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const T* __restrict__ dy, const 
 int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res,
                      void* dx, float* dg, float* db, int M, int D, hipStream_t s) {
   if (M <= 0) return 0;
+  if (ln_vec_ok(dy, x, dx, res, D) && !((uintptr_t)g & 15)) {
+    const int rpb = 16;
+    DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd_v<T>, dim3(fc_cdiv(M, rpb)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, g,
+                                       (const T*)res, (T*)dx, dg, db, M, D, rpb));
+    FC_LAUNCH_CHECK();
+    return 0;
+  }
   FC_REQUIRE(D <= 64 * LNB_MAXV, "layernorm_bwd: D=%d > %d unsupported", D, 64 * LNB_MAXV);
   DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(fc_cdiv(M, LNB_ROWS)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, g,
                                      (const T*)res, (T*)dx, dg, db, M, D));

@@ -72,6 +72,19 @@ enum { FC_GEMM_NT = 0, FC_GEMM_NN = 1, FC_GEMM_TN = 2 };
 int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K,
                  const GemmEpi& epi, hipStream_t s);
 
+// grouped weight-gradient GEMM: C[M,N] (fp32) = A[K,M]^T . B[K,N], bias_grad[M] = column sums of A (may be null)
+struct FcTnProblem {
+  const bf16_t* A;
+  const bf16_t* B;
+  float* C;
+  float* bias_grad;
+  int lda, ldb, ldc;
+  int M, N, K;
+  int tile_start, tiles_n;
+};
+int fc_gemm_tn_grouped_supported(const FcTnProblem& p);
+int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s);
+
 // ---- attention (K5).  qkv: [B,N,3,H,d] row-major (= the qkv GEMM output [B*N, 3*H*d]); o: [B,N,H*d]; lse: [B,H,N]
 int fc_attn_fwd_generic(int dt, const void* qkv, void* o, float* lse, int B, int N, int H, int d, float scale, hipStream_t s);
 int fc_attn_bwd_generic(int dt, const void* qkv, const void* o, const void* dout, const float* lse, float* delta,

@@ -252,6 +252,129 @@ k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B
   }
 }
 
+// ======================================================================== grouped weight-gradient GEMM
+// All dW = dY^T . X products of a backward pass (every linear of every layer of both towers) in ONE launch, each output
+// tile owned by exactly one workgroup that walks the whole reduction: no split-K, no atomics, bitwise reproducible.
+// The bias gradient (column sums of dY) falls out of the A-operand staging registers of the tile_n == 0 workgroups.
+__global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* __restrict__ probs, int nprob) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int nwg = gridDim.x, b = blockIdx.x;
+  int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+  int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  int pi = 0;
+  while (pi + 1 < nprob && probs[pi + 1].tile_start <= idx) ++pi;
+  const FcTnProblem P = probs[pi];
+  const int local = idx - P.tile_start;
+  const int tile_m = local / P.tiles_n, tile_n = local % P.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int M = P.M, N = P.N, K = P.K;
+  const int T = (K + BK - 1) / BK;
+  const bool do_colsum = (tile_n == 0) && (P.bias_grad != nullptr);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float cs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) cs[i] = 0.f;
+
+  uint4 ra[4], rb[4];
+  stage_load<KR>(ra, P.A, P.lda, m0, M, 0, K, tid);
+  stage_load<KR>(rb, P.B, P.ldb, n0, N, 0, K, tid);
+  stage_store<KR>(ra, smem, tid);
+  stage_store<KR>(rb, smem + 16384, tid);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    const char* la = smem + cur * 32768;
+    const char* lb = la + 16384;
+    if (do_colsum) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const bf16_t* hh = (const bf16_t*)&ra[p];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cs[i] += bf2f(hh[i]);
+      }
+    }
+    const bool more = (t + 1 < T);
+    if (more) {
+      stage_load<KR>(ra, P.A, P.lda, m0, M, (t + 1) * BK, K, tid);
+      stage_load<KR>(rb, P.B, P.ldb, n0, N, (t + 1) * BK, K, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag_read<KR>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = frag_read<KR>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      char* na = smem + (cur ^ 1) * 32768;
+      stage_store<KR>(ra, na, tid);
+      stage_store<KR>(rb, na + 16384, tid);
+    }
+    __syncthreads();
+  }
+  float* Cs = (float*)smem;
+  if (do_colsum) {  // thread (c = tid&15, kgroup = tid>>4) holds sums of columns 8c..8c+7 over its k rows
+    float* R = Cs;  // [16 kgroups][128 cols]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) R[(tid >> 4) * 128 + (tid & 15) * 8 + i] = cs[i];
+    __syncthreads();
+    if (tid < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int kg = 0; kg < 16; ++kg) s += R[kg * 128 + tid];
+      if (m0 + tid < M) P.bias_grad[m0 + tid] = s;
+    }
+    __syncthreads();
+  }
+  {
+    const int g = lane >> 4, cl = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) Cs[(wm * 64 + i * 16 + g * 4 + x) * CS_LD + wn * 64 + j * 16 + cl] = acc[i][j][x];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    int row = (tid >> 4) + 16 * p, c8 = (tid & 15) * 8;
+    int m = m0 + row, n = n0 + c8;
+    if (m < M && n < N) {
+      float4 x0 = *(const float4*)(Cs + row * CS_LD + c8), x1 = *(const float4*)(Cs + row * CS_LD + c8 + 4);
+      float* dst = P.C + (size_t)m * P.ldc + n;
+      *(float4*)dst = x0;
+      *(float4*)(dst + 4) = x1;
+    }
+  }
+}
+
+int fc_gemm_tn_grouped_supported(const FcTnProblem& p) {
+  return !((p.M & 7) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) ||
+           ((uintptr_t)p.C & 15));
+}
+int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s) {
+  if (nprob <= 0 || total_tiles <= 0) return 0;
+  const int lds = BM * CS_LD * 4;
+  static bool done = false;
+  if (!done) { FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_tn_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); done = true; }
+  hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(total_tiles), dim3(256), lds, s, probs_dev, nprob);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int AM, int BMo, typename TC, bool ATOM>

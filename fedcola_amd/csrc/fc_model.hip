@@ -42,6 +42,8 @@ struct TowerP {
 struct LastFwd { const void* ws = nullptr; int B = 0, n_txt = 0, feat_out = 0; const float* droppath = nullptr; const int64_t* ids = nullptr; };
 struct fc_model {
   mutable LastFwd last;
+  mutable std::vector<FcTnProblem> probs_host;   // last uploaded grouped-GEMM table (+ where it lives on the device)
+  mutable const void* probs_dev = nullptr;
   fc_model_cfg cfg;
   std::vector<fc_segment> segs;
   int64_t total = 0;
@@ -164,19 +166,24 @@ extern "C" size_t fc_compute_weights_bytes(const fc_model_t* m) { return m->need
 struct LayerWs {
   float *mean1, *rstd1, *mean2, *rstd2, *lse;
   void *h1, *qkv, *o, *xmid, *h2, *u, *gact;
+  // backward: every layer keeps its own dY tensors so that all weight gradients can be computed in one grouped launch
+  void *gxmid, *gdm, *gda, *gdu, *gdqkv;
 };
 struct TowerWs {
   int M = 0, N = 0;
   void *patches = nullptr, *dtok = nullptr;
   float *emb_mean = nullptr, *emb_rstd = nullptr;
   std::vector<void*> x;
+  std::vector<void*> gx;   // gradient w.r.t. x[l]
   std::vector<LayerWs> L;
   float *f, *hmean, *hrstd, *nrm, *out, *logits, *dlogits, *df;
 };
 struct Ws {
   TowerWs t[2];
-  void *dxa, *dxb, *dbig, *dqkv, *dh, *dO, *dxs;
+  void *dh, *dO;
   float *delta, *loss_scratch, *dout[2];
+  FcTnProblem* probs;   // device array for the grouped weight-gradient launch
+  int max_probs;
   int B, n_txt, feat_out;
   const float* droppath;
   const int64_t* ids;
@@ -219,8 +226,10 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
       t.emb_rstd = (float*)bp.take(sizeof(float) * t.M);
     }
     t.x.resize(c.depth + 1);
+    t.gx.resize(c.depth + 1);
     t.L.resize(c.depth);
     for (int l = 0; l <= c.depth; ++l) t.x[l] = bp.take((size_t)t.M * D * es);
+    for (int l = 0; l <= c.depth; ++l) t.gx[l] = bp.take((size_t)t.M * D * es);
     for (int l = 0; l < c.depth; ++l) {
       LayerWs& L = t.L[l];
       L.mean1 = (float*)bp.take(sizeof(float) * t.M);
@@ -235,6 +244,11 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
       L.h2 = bp.take((size_t)t.M * D * es);
       L.u = bp.take((size_t)t.M * Hd * es);
       L.gact = bp.take((size_t)t.M * Hd * es);
+      L.gxmid = bp.take((size_t)t.M * D * es);
+      L.gdm = bp.take((size_t)t.M * D * es);
+      L.gda = bp.take((size_t)t.M * D * es);
+      L.gdu = bp.take((size_t)t.M * Hd * es);
+      L.gdqkv = bp.take((size_t)t.M * 3 * D * es);
     }
     int nc = m->tw[i].ncls > 0 ? m->tw[i].ncls : 1;
     t.f = (float*)bp.take(sizeof(float) * (size_t)B * D);
@@ -247,13 +261,10 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
     t.df = (float*)bp.take(sizeof(float) * (size_t)B * D);
     w.dout[i] = (float*)bp.take(sizeof(float) * (size_t)B * (D > nc ? D : nc));
   }
-  w.dxa = bp.take((size_t)maxM * D * es);
-  w.dxb = bp.take((size_t)maxM * D * es);
-  w.dxs = bp.take((size_t)maxM * D * es);
   w.dh = bp.take((size_t)maxM * D * es);
   w.dO = bp.take((size_t)maxM * D * es);
-  w.dbig = bp.take((size_t)maxM * Hd * es);
-  w.dqkv = bp.take((size_t)maxM * 3 * D * es);
+  w.max_probs = 2 * (4 * c.depth + 1);
+  w.probs = (FcTnProblem*)bp.take(sizeof(FcTnProblem) * w.max_probs);
   int maxN = 0;
   for (int i = 0; i < 2; ++i) if (m->tw[i].present && w.t[i].N > maxN) maxN = w.t[i].N;
   w.delta = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * maxN);
@@ -310,6 +321,7 @@ struct Ctx {
   hipStream_t s;
   int dt;
   size_t es;
+  std::vector<FcTnProblem>* defer = nullptr;   // non-null: weight/bias gradients are queued for the grouped launch
   const void* W(int64_t off) const { return wc + (size_t)off * es; }
   // Y[M,N] = X[M,K] . W[N,K]^T
   int gemm_fwd(const void* X, const void* Wt, void* Y, int M, int N, int K, const GemmEpi& e) const {
@@ -461,10 +473,17 @@ extern "C" int fc_forward(const fc_model_t* m, const float* params, const void* 
 }
 
 // ---------------------------------------------------------------- backward
-static int linear_bwd_params(const Ctx& c, const LinearP& L, const void* dY, const void* X, int M, float* grads) {
-  FC_TRY(c.gemm_dw(dY, X, grads + L.w, M, L.out, L.in));
-  FC_TRY(fc_colsum(c.dt, dY, grads + L.b, M, L.out, 1, c.s));
+static int weight_grad(const Ctx& c, const void* dY, const void* X, int M, int out, int in, float* dW, float* db) {
+  if (c.defer) {
+    FcTnProblem p{(const bf16_t*)dY, (const bf16_t*)X, dW, db, out, in, in, out, in, M, 0, 0};
+    if (fc_gemm_tn_grouped_supported(p)) { c.defer->push_back(p); return 0; }
+  }
+  FC_TRY(c.gemm_dw(dY, X, dW, M, out, in));
+  FC_TRY(fc_colsum(c.dt, dY, db, M, out, 1, c.s));
   return 0;
+}
+static int linear_bwd_params(const Ctx& c, const LinearP& L, const void* dY, const void* X, int M, float* grads) {
+  return weight_grad(c, dY, X, M, L.out, L.in, grads + L.w, grads + L.b);
 }
 
 static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float* grads) {
@@ -484,42 +503,49 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
     FC_TRY(fc_colsum(FC_F32, d_out, grads + tp.head_b, B, tp.ncls, 1, c.s));
     din = t.df;
   }
-  void* dx = w.dxa;
-  void* dx2 = w.dxb;
-  FC_TRY(fc_head_bwd(c.dt, din, t.out, t.nrm, normalize, t.x[cf.depth], t.hmean, t.hrstd, P + m->normw, dx, grads + m->normw, grads + m->normb, B, N,
-                     D, c.s));
+  FC_TRY(fc_head_bwd(c.dt, din, t.out, t.nrm, normalize, t.x[cf.depth], t.hmean, t.hrstd, P + m->normw, t.gx[cf.depth], grads + m->normw,
+                     grads + m->normb, B, N, D, c.s));
   for (int l = cf.depth - 1; l >= 0; --l) {
     const BlockP& b = tp.blocks[l];
     LayerWs& L = t.L[l];
+    const void* dx = t.gx[l + 1];
     // ---- MLP branch: x_{l+1} = xmid + s2 * (gact.W2^T + b2)
     const float* s2 = dp_ptr(m, w.droppath, i, l, 1, B);
     const void* dm = dx;
-    if (s2) { FC_TRY(rowscale(c.dt, dx, w.dxs, s2, N, M, D, c.s)); dm = w.dxs; }
+    if (s2) { FC_TRY(rowscale(c.dt, dx, L.gdm, s2, N, M, D, c.s)); dm = L.gdm; }
     FC_TRY(linear_bwd_params(c, b.fc2, dm, L.gact, M, grads));
-    { GemmEpi e; e.gelu_in = L.u; FC_TRY(c.gemm_dx(dm, c.W(b.fc2.w), w.dbig, M, D, Hd, e)); }                 // du = (dm.W2) * gelu'(u)
-    FC_TRY(linear_bwd_params(c, b.fc1, w.dbig, L.h2, M, grads));
-    { GemmEpi e; FC_TRY(c.gemm_dx(w.dbig, c.W(b.fc1.w), w.dh, M, Hd, D, e)); }                                 // dh2
-    FC_TRY(fc_layernorm_bwd(c.dt, w.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, dx, dx2, grads + b.n2w, grads + b.n2b, M, D, c.s));  // dxmid
+    { GemmEpi e; e.gelu_in = L.u; FC_TRY(c.gemm_dx(dm, c.W(b.fc2.w), L.gdu, M, D, Hd, e)); }                  // du = (dm.W2) * gelu'(u)
+    FC_TRY(linear_bwd_params(c, b.fc1, L.gdu, L.h2, M, grads));
+    { GemmEpi e; FC_TRY(c.gemm_dx(L.gdu, c.W(b.fc1.w), w.dh, M, Hd, D, e)); }                                  // dh2
+    FC_TRY(fc_layernorm_bwd(c.dt, w.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, dx, L.gxmid, grads + b.n2w, grads + b.n2b, M, D, c.s));
     // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp)
     const float* s1 = dp_ptr(m, w.droppath, i, l, 0, B);
-    const void* da = dx2;
-    if (s1) { FC_TRY(rowscale(c.dt, dx2, w.dxs, s1, N, M, D, c.s)); da = w.dxs; }
+    const void* da = L.gxmid;
+    if (s1) { FC_TRY(rowscale(c.dt, L.gxmid, L.gda, s1, N, M, D, c.s)); da = L.gda; }
     FC_TRY(linear_bwd_params(c, b.proj, da, L.o, M, grads));
     { GemmEpi e; FC_TRY(c.gemm_dx(da, c.W(b.proj.w), w.dO, M, D, D, e)); }
-    FC_TRY(c.attn_bwd(L.qkv, L.o, w.dO, L.lse, w.delta, w.dqkv, B, N));
-    FC_TRY(linear_bwd_params(c, b.qkv, w.dqkv, L.h1, M, grads));
-    { GemmEpi e; FC_TRY(c.gemm_dx(w.dqkv, c.W(b.qkv.w), w.dh, M, 3 * D, D, e)); }                               // dh1
-    FC_TRY(fc_layernorm_bwd(c.dt, w.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, dx2, dx, grads + b.n1w, grads + b.n1b, M, D, c.s));  // dx_l
+    FC_TRY(c.attn_bwd(L.qkv, L.o, w.dO, L.lse, w.delta, L.gdqkv, B, N));
+    FC_TRY(linear_bwd_params(c, b.qkv, L.gdqkv, L.h1, M, grads));
+    { GemmEpi e; FC_TRY(c.gemm_dx(L.gdqkv, c.W(b.qkv.w), w.dh, M, 3 * D, D, e)); }                             // dh1
+    FC_TRY(fc_layernorm_bwd(c.dt, w.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, L.gxmid, t.gx[l], grads + b.n1w, grads + b.n1b, M, D, c.s));
   }
+  const void* dx = t.gx[0];
   if (i == 0) {
     int np = N - 1, kp = cf.in_chans * cf.patch * cf.patch;
     FC_TRY(fc_img_embed_bwd(c.dt, dx, grads + tp.pos, grads + tp.cls, t.dtok, B, N, D, c.s));
-    FC_TRY(c.gemm_dw(t.dtok, t.patches, grads + tp.pw, B * np, D, kp));
-    FC_TRY(fc_colsum(c.dt, t.dtok, grads + tp.pb, B * np, D, 1, c.s));
+    FC_TRY(weight_grad(c, t.dtok, t.patches, B * np, D, kp, grads + tp.pw, grads + tp.pb));
   } else {
     FC_TRY(fc_txt_embed_bwd(c.dt, dx, w.ids, P + tp.word, P + tp.tpos, P + tp.ttype, t.emb_mean, t.emb_rstd, P + tp.lnw, grads + tp.word,
                             grads + tp.tpos, grads + tp.ttype, grads + tp.lnw, grads + tp.lnb, B, N, D, cf.vocab, c.s));
   }
+  return 0;
+}
+
+// CrossModalReparamLinear: route dW_eff (mome.py:58-60).  Runs after the weight gradients exist (i.e. after the grouped launch).
+static int tower_reparam_grads(const Ctx& c, int i, float* grads) {
+  const fc_model* m = c.m;
+  const TowerP& tp = m->tw[i];
+  const float* P = c.params;
   // CrossModalReparamLinear: route dW_eff (mome.py:58-60)
   for (const BlockP& b : tp.blocks) {
     const LinearP* Ls[4] = {&b.qkv, &b.proj, &b.fc1, &b.fc2};
@@ -535,8 +561,31 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
 static int backward_impl(const fc_model* m, const float* params, const void* wc, const float* d_out_img, const float* d_out_txt, float* grads,
                          Ws& w, hipStream_t s) {
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
+  std::vector<FcTnProblem> probs;
+  if (m->dt == FC_BF16) c.defer = &probs;   // all dW / db products of this backward go into one grouped MFMA launch
   if (m->tw[0].present && d_out_img) FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
   if (m->tw[1].present && d_out_txt) FC_TRY(tower_backward(c, w, 1, d_out_txt, grads));
+  if (!probs.empty()) {
+    FC_REQUIRE((int)probs.size() <= w.max_probs, "internal: too many deferred weight-gradient problems");
+    int tiles = 0;
+    for (FcTnProblem& p : probs) {
+      p.tile_start = tiles;
+      p.tiles_n = fc_cdiv(p.N, 128);
+      tiles += fc_cdiv(p.M, 128) * p.tiles_n;
+    }
+    // the table only depends on buffer addresses and shapes: re-upload only when it changed
+    bool same = m->probs_dev == w.probs && m->probs_host.size() == probs.size() &&
+                memcmp(m->probs_host.data(), probs.data(), probs.size() * sizeof(FcTnProblem)) == 0;
+    if (!same) {
+      FC_CHECK_HIP(hipStreamSynchronize(s));   // the previous table may still be in use by an earlier launch
+      m->probs_host = probs;
+      m->probs_dev = w.probs;
+      FC_CHECK_HIP(hipMemcpyAsync(w.probs, m->probs_host.data(), probs.size() * sizeof(FcTnProblem), hipMemcpyHostToDevice, s));
+    }
+    FC_TRY(fc_gemm_tn_grouped(w.probs, (int)probs.size(), tiles, s));
+  }
+  if (m->tw[0].present && d_out_img) FC_TRY(tower_reparam_grads(c, 0, grads));
+  if (m->tw[1].present && d_out_txt) FC_TRY(tower_reparam_grads(c, 1, grads));
   return 0;
 }
 
