@@ -90,4 +90,5 @@ struct GemmEpi {
   float alpha = 1.0f;               // result = alpha*acc (+bias...)
   int patch_rows = 0;               // >0: patch-embed remap: out row = m + m/patch_rows + 1, adds pos[1 + m%patch_rows]
   const float* pos = nullptr;       // [1+patch_rows, N] fp32
+  int dbg = 0;                      // development ablations (FC_GEMM_DBG): 1 = no global loads in the loop, 2 = no epilogue, 4 = no MFMA
 };

@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(256) k_ln_fwd_v(const T* __restrict__ x, const
 template <typename T>
 __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ g, const T* res, T* dx,
-                                                  float* __restrict__ dg, float* __restrict__ db, int M, int D, int rows_per_block) {
+                                                  float* __restrict__ dg, float* __restrict__ db, int M, int D, int rows_per_block,
+                                                  float* __restrict__ partial) {
   __shared__ float red[2][4][1024];
   int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nc = D >> 3;
@@ -159,10 +160,41 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
     }
   }
   __syncthreads();
+  if (partial) {  // [block][dg(D) | db(D)], reduced later by k_ln_reduce_grouped (no same-address atomic storm)
+    float* pp = partial + (size_t)blockIdx.x * 2 * D;
+    for (int i = threadIdx.x; i < D; i += 256) {
+      pp[i] = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
+      pp[D + i] = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < D; i += 256) {
     atomicAdd(dg + i, red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
     atomicAdd(db + i, red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
   }
+}
+
+// grouped reduction of the LayerNorm-backward partials: block (x = column chunk of 64, y = LN instance)
+__global__ void __launch_bounds__(256) k_ln_reduce_grouped(const FcLnReduce* __restrict__ tab) {
+  __shared__ float red[4][64];
+  const FcLnReduce e = tab[blockIdx.y];
+  int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  int W = 2 * e.D;
+  float acc = 0.f;
+  if (col < W)
+    for (int bk = wave; bk < e.nblocks; bk += 4) acc += e.partial[(size_t)bk * W + col];
+  red[wave][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (wave == 0 && col < W) {
+    float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (col < e.D) atomicAdd(e.dg + col, v); else atomicAdd(e.db + col - e.D, v);
+  }
+}
+int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_ln_reduce_grouped, dim3(fc_cdiv(2 * maxD, 64), n), dim3(256), 0, s, tab_dev);
+  FC_LAUNCH_CHECK();
+  return 0;
 }
 
 static bool ln_vec_ok(const void* a, const void* b, const void* c, const void* d, int D) {
@@ -240,15 +272,17 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const T* __restrict__ dy, const 
   }
 }
 
+int fc_layernorm_bwd_partial_blocks(int M) { return fc_cdiv(M, 16); }
+
 int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res,
-                     void* dx, float* dg, float* db, int M, int D, hipStream_t s) {
+                     void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial) {
   if (M <= 0) return 0;
   if (ln_vec_ok(dy, x, dx, res, D) && !((uintptr_t)g & 15)) {
     const int rpb = 16;
     DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd_v<T>, dim3(fc_cdiv(M, rpb)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, g,
-                                       (const T*)res, (T*)dx, dg, db, M, D, rpb));
+                                       (const T*)res, (T*)dx, dg, db, M, D, rpb, partial));
     FC_LAUNCH_CHECK();
-    return 0;
+    return partial ? 1 : 0;   // 1: dg/db are pending in `partial` (caller queues the grouped reduction)
   }
   FC_REQUIRE(D <= 64 * LNB_MAXV, "layernorm_bwd: D=%d > %d unsupported", D, 64 * LNB_MAXV);
   DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(fc_cdiv(M, LNB_ROWS)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, g,

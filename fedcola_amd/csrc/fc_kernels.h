@@ -13,9 +13,19 @@ static inline size_t fc_esize(int dt) { return dt == FC_BF16 ? 2 : 4; }
 // ---- layer norm (K3)
 int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
                      int M, int D, float eps, hipStream_t s);
-// dx = (res ? res : 0) + LNbwd(dy); dg/db accumulated (atomics) into fp32 grads
+// dx = (res ? res : 0) + LNbwd(dy); dg/db accumulated (atomics) into fp32 grads.  With `partial` (room for
+// fc_layernorm_bwd_partial_blocks(M)*2*D floats) the vector kernel writes per-block partial sums there instead and the
+// call returns 1: the caller must then run fc_ln_reduce_grouped over its queued FcLnReduce entries.
+struct FcLnReduce {
+  const float* partial;
+  float* dg;
+  float* db;
+  int nblocks, D;
+};
+int fc_layernorm_bwd_partial_blocks(int M);
 int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
-                     const void* res, void* dx, float* dg, float* db, int M, int D, hipStream_t s);
+                     const void* res, void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial = nullptr);
+int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s);
 
 // ---- image embedding (K1): patches[B*np, C*P*P] (conv-weight order), cls rows, and backward pieces
 int fc_patchify(int dt, const float* img, void* patches, int B, int C, int HW, int P, hipStream_t s);

@@ -14,6 +14,8 @@
 // Epilogue: accumulators -> LDS (fp32, padded rows) -> 8 consecutive columns per thread -> fused bias / GELU(+pre-act
 // store) / GELU' multiply / drop-path row scale / residual / patch-embed row remap, 16-byte global stores.
 // Block ids are remapped so that the tiles sharing an A row-panel run on the same XCD (private L2).
+#include <stdlib.h>
+
 #include "fc_kernels.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -32,22 +34,54 @@ __device__ __forceinline__ int kr_off(int k, int c) {
   return k * 256 + (((c >> 1) ^ s) << 5) + ((c & 1) << 4);
 }
 
-// ---- staging: each thread moves 4 x 16 B per operand per k-tile
+// ---- staging: each thread moves 4 x 16 B per operand per k-tile.
+// Loads are raw buffer loads: one wave-uniform descriptor (SGPRs) + a 32-bit per-lane byte offset that is constant over
+// the k loop + a scalar k offset, so the address arithmetic costs no VGPRs; out-of-range rows of the last tile fall
+// outside the descriptor and read as zero in hardware.
+typedef __attribute__((vector_size(16))) unsigned int v4u;
+struct Operand {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff[4];   // per-lane byte offsets of the 4 pieces (k-independent)
+  unsigned kstride;   // bytes per k element (KC: 2) or per k row (KR: 2*ld)
+  int c8;             // KC only: first k of this lane's 16-B chunk inside a tile
+};
+#define FC_OOB 0x80000000u
 template <int MODE>
-__device__ __forceinline__ void stage_load(uint4 (&r)[4], const bf16_t* __restrict__ P, long ld, int row0, int nrows, int k0, int K, int tid) {
+__device__ __forceinline__ Operand make_operand(const bf16_t* P, long ld, int row0, int nrows, int K, int tid) {
+  Operand o;
+  // total extent in bytes (rows x ld for KC, K x ld for KR); the pointer and sizes are wave-uniform by construction
+  unsigned long long base = (unsigned long long)P;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+  const void* up = (const void*)(((unsigned long long)hi << 32) | lo);
+  long rows = (MODE == KC) ? nrows : K;
+  unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(((rows - 1) * ld + ((MODE == KC) ? K : nrows)) * 2));
+  o.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)up, 0, (int)bytes, 0x00020000);
+  if (MODE == KC) {  // P[row][k]: lane chunk c = tid&7, rows (tid>>3) + 32p
+    o.c8 = (tid & 7) * 8;
+    o.kstride = 2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int r = row0 + (tid >> 3) + 32 * p;
+      o.voff[p] = r < nrows ? (unsigned)((r * ld + o.c8) * 2) : FC_OOB;
+    }
+  } else {  // P[k][col]: lane chunk c = tid&15, k rows (tid>>4) + 16p
+    o.c8 = 0;
+    o.kstride = (unsigned)(ld * 2);
+    int col = row0 + (tid & 15) * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o.voff[p] = col < nrows ? (unsigned)((((tid >> 4) + 16 * p) * ld + col) * 2) : FC_OOB;
+  }
+  return o;
+}
+template <int MODE>
+__device__ __forceinline__ void stage_load(uint4 (&r)[4], const Operand& o, int k0, int K) {
+  const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)k0 * o.kstride));   // scalar offset (SGPR)
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (MODE == KC) {  // P[row][k]
-      int c = tid & 7, row = (tid >> 3) + 32 * p;
-      int gr = row0 + row, gk = k0 + c * 8;
-      if (gr < nrows && gk < K) v = *(const uint4*)(P + (size_t)gr * ld + gk);
-    } else {  // P[k][col]
-      int c = tid & 15, k = (tid >> 4) + 16 * p;
-      int gk = k0 + k, gc = row0 + c * 8;
-      if (gk < K && gc < nrows) v = *(const uint4*)(P + (size_t)gk * ld + gc);
-    }
-    r[p] = v;
+    unsigned vo = o.voff[p];
+    if (MODE == KC) vo = (k0 + o.c8 < K) ? vo : FC_OOB;   // k tail of the last tile (K % 64 != 0)
+    v4u v = __builtin_amdgcn_raw_buffer_load_b128(o.rsrc, vo, soff, 0);
+    r[p] = *(uint4*)&v;
   }
 }
 template <int MODE>
@@ -112,7 +146,7 @@ template <> struct Vec8<float> {
   }
 };
 
-template <typename TC, bool ATOMIC>
+template <typename TC>
 __device__ __forceinline__ void epi_store8(TC* C, long ldc, int m, int n, float (&v)[8], const GemmEpi& e, int N) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
@@ -153,92 +187,123 @@ __device__ __forceinline__ void epi_store8(TC* C, long ldc, int m, int n, float 
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += r[i];
   }
-  if (ATOMIC) {
+  if (e.accumulate) {
+    float r[8];
+    Vec8<TC>::ld(C + o, r);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd((float*)C + o + i, v[i]);
-  } else {
-    if (e.accumulate) {
-      float r[8];
-      Vec8<TC>::ld(C + o, r);
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  Vec8<TC>::st(C + o, v);
+}
+
+// accumulators -> LDS image (fp32, rows padded to CS_LD): lane (g, cl) owns C[16i + cl][16j + 4g .. +3] (swapped operands)
+__device__ __forceinline__ void acc_to_lds(float* Cs, const f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+  const int g = lane >> 4, cl = lane & 15;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] += r[i];
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *(float4*)(Cs + (wm * 64 + i * 16 + cl) * CS_LD + wn * 64 + j * 16 + 4 * g) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+}
+
+
+
+// ---- main loop shared by the single-problem and the grouped kernels.
+// Operands are swapped in the MFMA (D' = B.A^T) so that acc[i][j][x] = C[m = 16i + lane&15][n = 16j + 4(lane>>4) + x]:
+// a lane then owns 4 consecutive output columns and the epilogue needs no LDS round trip.
+// Two register sets keep TWO k-tiles of global loads in flight behind the MFMAs (load -> use distance = 2 tiles).
+struct StageRegs { uint4 a[4], b[4]; };
+
+template <int AMODE, int BMODE>
+__device__ __forceinline__ void tile_load(StageRegs& R, const Operand& oa, const Operand& ob, int k0, int K) {
+  stage_load<AMODE>(R.a, oa, k0, K);
+  stage_load<BMODE>(R.b, ob, k0, K);
+}
+template <int AMODE, int BMODE, bool COLSUM>
+__device__ __forceinline__ void tile_store(const StageRegs& R, char* buf, int tid, float (&cs)[8], bool do_colsum) {
+  stage_store<AMODE>(R.a, buf, tid);
+  stage_store<BMODE>(R.b, buf + 16384, tid);
+  if (COLSUM && do_colsum) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const bf16_t* hh = (const bf16_t*)&R.a[p];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cs[i] += bf2f(hh[i]);
     }
-    Vec8<TC>::st(C + o, v);
+  }
+}
+template <int AMODE, int BMODE>
+__device__ __forceinline__ void tile_compute(const char* buf, f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+  const char* la = buf;
+  const char* lb = buf + 16384;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = frag_read<AMODE>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BMODE>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
   }
 }
 
-template <int AMODE, int BMODE, typename TC, bool ATOMIC>
+template <int AMODE, int BMODE, bool COLSUM>
+__device__ __forceinline__ void gemm_mainloop(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bm, long ldb, int m0, int n0, int M,
+                                              int N, int K, char* smem, f32x4 (&acc)[4][4], float (&cs)[8], bool do_colsum, int tid, int wm, int wn,
+                                              int lane, int dbg = 0) {
+  const int T = (K + BK - 1) / BK;
+  char* buf0 = smem;
+  char* buf1 = smem + 32768;
+  StageRegs R0, R1;
+  const Operand oa = make_operand<AMODE>(A, lda, m0, M, K, tid);
+  const Operand ob = make_operand<BMODE>(Bm, ldb, n0, N, K, tid);
+  // Loads past the last tile fall outside the descriptor (zeros) and their stores go to a buffer nobody reads again, so
+  // the loop body is branch-free: hipcc can then count the loads in flight (s_waitcnt vmcnt(8), never 0, inside the loop).
+  tile_load<AMODE, BMODE>(R0, oa, ob, 0, K);
+  tile_load<AMODE, BMODE>(R1, oa, ob, BK, K);
+  tile_store<AMODE, BMODE, COLSUM>(R0, buf0, tid, cs, do_colsum);
+  __syncthreads();
+  for (int t = 0; t < T; t += 2) {
+    if (!(dbg & 1)) tile_load<AMODE, BMODE>(R0, oa, ob, (t + 2) * BK, K);
+    if (!(dbg & 4)) tile_compute<AMODE, BMODE>(buf0, acc, wm, wn, lane);
+    tile_store<AMODE, BMODE, COLSUM>(R1, buf1, tid, cs, do_colsum);
+    __syncthreads();
+    if (!(dbg & 1)) tile_load<AMODE, BMODE>(R1, oa, ob, (t + 3) * BK, K);
+    if (!(dbg & 4)) tile_compute<AMODE, BMODE>(buf1, acc, wm, wn, lane);   // an odd T ends on an all-zero tile: adds nothing
+    tile_store<AMODE, BMODE, COLSUM>(R0, buf0, tid, cs, do_colsum);
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {  // blocks b, b+8, ... share an XCD: give each XCD a contiguous id range
+  int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+template <int AMODE, int BMODE, typename TC>
 __global__ void __launch_bounds__(256, 2)
-k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bm, long ldb, TC* C, long ldc, int M, int N, int K,
-            int tiles_n, int ktiles_per_split, GemmEpi e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A 16 KB | B 16 KB); reused as Cs[128][CS_LD] fp32
+k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bm, long ldb, TC* C, long ldc, int M, int N, int K, int tiles_n,
+            GemmEpi e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A 16 KB | B 16 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware bijective remap of the tile id (blocks b, b+8, ... share an XCD)
-  int nwg = gridDim.x, b = blockIdx.x;
-  int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-  int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  const int tile_m = idx / tiles_n, tile_n = idx % tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int T = (K + BK - 1) / BK;
-  const int t_beg = blockIdx.y * ktiles_per_split;
-  const int t_end = min(T, t_beg + ktiles_per_split);
-
+  const int idx = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (idx / tiles_n) * BM, n0 = (idx % tiles_n) * BN;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  uint4 ra[4], rb[4];
-  if (t_beg < t_end) {
-    stage_load<AMODE>(ra, A, lda, m0, M, t_beg * BK, K, tid);
-    stage_load<BMODE>(rb, Bm, ldb, n0, N, t_beg * BK, K, tid);
-    stage_store<AMODE>(ra, smem, tid);
-    stage_store<BMODE>(rb, smem + 16384, tid);
-  }
-  __syncthreads();
-  for (int t = t_beg; t < t_end; ++t) {
-    const int cur = (t - t_beg) & 1;
-    const char* la = smem + cur * 32768;
-    const char* lb = la + 16384;
-    const bool more = (t + 1 < t_end);
-    if (more) {
-      stage_load<AMODE>(ra, A, lda, m0, M, (t + 1) * BK, K, tid);
-      stage_load<BMODE>(rb, Bm, ldb, n0, N, (t + 1) * BK, K, tid);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = frag_read<AMODE>(la, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BMODE>(lb, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      char* na = smem + (cur ^ 1) * 32768;
-      stage_store<AMODE>(ra, na, tid);
-      stage_store<BMODE>(rb, na + 16384, tid);
-    }
-    __syncthreads();
-  }
-  // ---- epilogue through LDS (all waves are past the last barrier: the staging buffers are free)
+  float cs[8];
+  gemm_mainloop<AMODE, BMODE, false>(A, lda, Bm, ldb, m0, n0, M, N, K, smem, acc, cs, false, tid, wm, wn, lane, e.dbg);
+  if ((e.dbg & 2) && acc[0][0][0] != 123.456f) return;
+  // epilogue through LDS: whole 256-B (bf16) / 512-B (fp32) row segments per 16 lanes, 16-byte accesses
   float* Cs = (float*)smem;
-  {
-    const int g = lane >> 4, cl = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) Cs[(wm * 64 + i * 16 + g * 4 + x) * CS_LD + wn * 64 + j * 16 + cl] = acc[i][j][x];
-  }
+  acc_to_lds(Cs, acc, wm, wn, lane);
   __syncthreads();
-  if (ATOMIC && t_beg >= t_end) return;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     int row = (tid >> 4) + 16 * p, c8 = (tid & 15) * 8;
@@ -247,7 +312,7 @@ k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B
       float v[8];
       float4 x0 = *(const float4*)(Cs + row * CS_LD + c8), x1 = *(const float4*)(Cs + row * CS_LD + c8 + 4);
       v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-      epi_store8<TC, ATOMIC>(C, ldc, m, n, v, e, N);
+      epi_store8<TC>(C, ldc, m, n, v, e, N);
     }
   }
 }
@@ -260,19 +325,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* _
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  int nwg = gridDim.x, b = blockIdx.x;
-  int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-  int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int idx = xcd_remap(blockIdx.x, gridDim.x);
   int pi = 0;
   while (pi + 1 < nprob && probs[pi + 1].tile_start <= idx) ++pi;
   const FcTnProblem P = probs[pi];
   const int local = idx - P.tile_start;
   const int tile_m = local / P.tiles_n, tile_n = local % P.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int M = P.M, N = P.N, K = P.K;
-  const int T = (K + BK - 1) / BK;
+  const int M = P.M, N = P.N;
   const bool do_colsum = (tile_n == 0) && (P.bias_grad != nullptr);
-
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -281,82 +342,31 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* _
   float cs[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) cs[i] = 0.f;
-
-  uint4 ra[4], rb[4];
-  stage_load<KR>(ra, P.A, P.lda, m0, M, 0, K, tid);
-  stage_load<KR>(rb, P.B, P.ldb, n0, N, 0, K, tid);
-  stage_store<KR>(ra, smem, tid);
-  stage_store<KR>(rb, smem + 16384, tid);
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const int cur = t & 1;
-    const char* la = smem + cur * 32768;
-    const char* lb = la + 16384;
-    if (do_colsum) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const bf16_t* hh = (const bf16_t*)&ra[p];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) cs[i] += bf2f(hh[i]);
-      }
-    }
-    const bool more = (t + 1 < T);
-    if (more) {
-      stage_load<KR>(ra, P.A, P.lda, m0, M, (t + 1) * BK, K, tid);
-      stage_load<KR>(rb, P.B, P.ldb, n0, N, (t + 1) * BK, K, tid);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = frag_read<KR>(la, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = frag_read<KR>(lb, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      char* na = smem + (cur ^ 1) * 32768;
-      stage_store<KR>(ra, na, tid);
-      stage_store<KR>(rb, na + 16384, tid);
-    }
-    __syncthreads();
-  }
-  float* Cs = (float*)smem;
+  gemm_mainloop<KR, KR, true>(P.A, P.lda, P.B, P.ldb, m0, n0, M, N, P.K, smem, acc, cs, do_colsum, tid, wm, wn, lane);
   if (do_colsum) {  // thread (c = tid&15, kgroup = tid>>4) holds sums of columns 8c..8c+7 over its k rows
-    float* R = Cs;  // [16 kgroups][128 cols]
+    float* R = (float*)smem;  // [16 kgroups][128 cols]; the staging buffers are free after the main loop's last barrier
 #pragma unroll
     for (int i = 0; i < 8; ++i) R[(tid >> 4) * 128 + (tid & 15) * 8 + i] = cs[i];
     __syncthreads();
     if (tid < 128) {
-      float s = 0.f;
+      float sum = 0.f;
 #pragma unroll
-      for (int kg = 0; kg < 16; ++kg) s += R[kg * 128 + tid];
-      if (m0 + tid < M) P.bias_grad[m0 + tid] = s;
+      for (int kg = 0; kg < 16; ++kg) sum += R[kg * 128 + tid];
+      if (m0 + tid < M) P.bias_grad[m0 + tid] = sum;
     }
-    __syncthreads();
   }
-  {
-    const int g = lane >> 4, cl = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) Cs[(wm * 64 + i * 16 + g * 4 + x) * CS_LD + wn * 64 + j * 16 + cl] = acc[i][j][x];
-  }
+  __syncthreads();
+  float* Cs = (float*)smem;
+  acc_to_lds(Cs, acc, wm, wn, lane);
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     int row = (tid >> 4) + 16 * p, c8 = (tid & 15) * 8;
     int m = m0 + row, n = n0 + c8;
     if (m < M && n < N) {
-      float4 x0 = *(const float4*)(Cs + row * CS_LD + c8), x1 = *(const float4*)(Cs + row * CS_LD + c8 + 4);
       float* dst = P.C + (size_t)m * P.ldc + n;
-      *(float4*)dst = x0;
-      *(float4*)(dst + 4) = x1;
+      *(float4*)dst = *(const float4*)(Cs + row * CS_LD + c8);
+      *(float4*)(dst + 4) = *(const float4*)(Cs + row * CS_LD + c8 + 4);
     }
   }
 }
@@ -377,56 +387,48 @@ int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles,
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-template <int AM, int BMo, typename TC, bool ATOM>
-static int launch_gemm(dim3 grid, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K, int tiles_n,
-                       int kps, const GemmEpi& epi, hipStream_t s) {
-  const int lds = BM * CS_LD * 4;  // 67,584 B (> the 65,536 B staging image)
-  auto kfn = k_gemm_mfma<AM, BMo, TC, ATOM>;
+template <int AM, int BMo, typename TC>
+static int launch_gemm(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K, int tiles_n,
+                       const GemmEpi& epi, hipStream_t s) {
+  const int lds = BM * CS_LD * 4;
+  auto kfn = k_gemm_mfma<AM, BMo, TC>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, A, lda, Bm, ldb, (TC*)C, ldc, M, N, K, tiles_n, kps, epi);
+  hipLaunchKernelGGL(kfn, dim3(tiles), dim3(256), lds, s, A, lda, Bm, ldb, (TC*)C, ldc, M, N, K, tiles_n, epi);
   FC_LAUNCH_CHECK();
   return 0;
 }
 
 int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K,
-                 const GemmEpi& epi, hipStream_t s) {
+                 const GemmEpi& epi_in, hipStream_t s) {
+  const GemmEpi& epi0 = epi_in;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   // vector-width constraints of this kernel; anything else goes to the generic path
   if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 7) || !aligned16(A) || !aligned16(Bm) || !aligned16(C)) return 1;
   if (kind != FC_GEMM_TN && (K & 7)) return 1;
   if (kind == FC_GEMM_TN && (M & 7)) return 1;
-  if (epi.bias && !aligned16(epi.bias)) return 1;
-  if (epi.res && !aligned16(epi.res)) return 1;
-  if (epi.preact && !aligned16(epi.preact)) return 1;
-  if (epi.gelu_in && !aligned16(epi.gelu_in)) return 1;
-  if (epi.pos && !aligned16(epi.pos)) return 1;
-  int tiles_m = fc_cdiv(M, BM), tiles_n = fc_cdiv(N, BN);
-  int tiles = tiles_m * tiles_n;
-  int T = fc_cdiv(K, BK);
+  if (epi0.bias && !aligned16(epi0.bias)) return 1;
+  if (epi0.res && !aligned16(epi0.res)) return 1;
+  if (epi0.preact && !aligned16(epi0.preact)) return 1;
+  if (epi0.gelu_in && !aligned16(epi0.gelu_in)) return 1;
+  if (epi0.pos && !aligned16(epi0.pos)) return 1;
+  int tiles_n = fc_cdiv(N, BN);
+  int tiles = fc_cdiv(M, BM) * tiles_n;
+  static int dbg = getenv("FC_GEMM_DBG") ? atoi(getenv("FC_GEMM_DBG")) : 0;
+  GemmEpi epi = epi_in;
+  epi.dbg = dbg;
   if (kind == FC_GEMM_NT) {
-    if (dtC == FC_BF16) return launch_gemm<KC, KC, bf16_t, false>(dim3(tiles, 1), A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, T, epi, s);
-    return launch_gemm<KC, KC, float, false>(dim3(tiles, 1), A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, T, epi, s);
+    if (dtC == FC_BF16) return launch_gemm<KC, KC, bf16_t>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
+    return launch_gemm<KC, KC, float>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
   }
   if (kind == FC_GEMM_NN) {
-    if (dtC == FC_BF16) return launch_gemm<KC, KR, bf16_t, false>(dim3(tiles, 1), A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, T, epi, s);
-    return launch_gemm<KC, KR, float, false>(dim3(tiles, 1), A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, T, epi, s);
+    if (dtC == FC_BF16) return launch_gemm<KC, KR, bf16_t>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
+    return launch_gemm<KC, KR, float>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
   }
+  // single TN problem (weight gradients normally go through fc_gemm_tn_grouped instead)
   if (dtC != FC_F32) return 1;
-  // TN (weight gradients): split the long reduction so that ~2 workgroups per CU are in flight; the partial tiles are
-  // combined with fp32 atomics into a zeroed (or accumulating) output
-  bool plain = !epi.bias && !epi.res && !epi.preact && !epi.gelu_in && !epi.rowscale && epi.patch_rows == 0;
-  int splits = plain ? (512 + tiles - 1) / tiles : 1;
-  if (splits > T) splits = T;
-  if (splits < 1) splits = 1;
-  int kps = fc_cdiv(T, splits);
-  splits = fc_cdiv(T, kps);
-  if (splits == 1) return launch_gemm<KR, KR, float, false>(dim3(tiles, 1), A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, T, epi, s);
-  if (!epi.accumulate && !epi.out_zeroed) FC_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, s));
-  GemmEpi e2 = epi;
-  e2.accumulate = 0;
-  return launch_gemm<KR, KR, float, true>(dim3(tiles, splits), A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, kps, e2, s);
+  return launch_gemm<KR, KR, float>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
 }

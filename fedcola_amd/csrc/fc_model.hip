@@ -44,6 +44,16 @@ struct fc_model {
   mutable LastFwd last;
   mutable std::vector<FcTnProblem> probs_host;   // last uploaded grouped-GEMM table (+ where it lives on the device)
   mutable const void* probs_dev = nullptr;
+  mutable std::vector<FcLnReduce> ln_host;        // same for the grouped LayerNorm-gradient reduction
+  mutable const void* ln_dev = nullptr;
+  // the two towers are independent until the loss: the text tower runs on a side stream, forked/joined with events
+  mutable hipStream_t side = nullptr;
+  mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  ~fc_model() {
+    if (side) (void)hipStreamDestroy(side);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+  }
   fc_model_cfg cfg;
   std::vector<fc_segment> segs;
   int64_t total = 0;
@@ -177,13 +187,16 @@ struct TowerWs {
   std::vector<void*> gx;   // gradient w.r.t. x[l]
   std::vector<LayerWs> L;
   float *f, *hmean, *hrstd, *nrm, *out, *logits, *dlogits, *df;
+  void *dh, *dO;          // backward temporaries (per tower: the towers run concurrently)
+  float *delta;
+  float *ln_partial;      // [2*depth][blocks][2*D] LayerNorm-backward partial sums
 };
 struct Ws {
   TowerWs t[2];
-  void *dh, *dO;
-  float *delta, *loss_scratch, *dout[2];
+  float *loss_scratch, *dout[2];
   FcTnProblem* probs;   // device array for the grouped weight-gradient launch
-  int max_probs;
+  FcLnReduce* lntab;    // device array for the grouped LayerNorm-gradient reduction
+  int max_probs, max_ln;
   int B, n_txt, feat_out;
   const float* droppath;
   const int64_t* ids;
@@ -260,14 +273,15 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
     t.dlogits = (float*)bp.take(sizeof(float) * (size_t)B * nc);
     t.df = (float*)bp.take(sizeof(float) * (size_t)B * D);
     w.dout[i] = (float*)bp.take(sizeof(float) * (size_t)B * (D > nc ? D : nc));
+    t.dh = bp.take((size_t)t.M * D * es);
+    t.dO = bp.take((size_t)t.M * D * es);
+    t.delta = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * t.N);
+    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)2 * c.depth * fc_layernorm_bwd_partial_blocks(t.M) * 2 * D);
   }
-  w.dh = bp.take((size_t)maxM * D * es);
-  w.dO = bp.take((size_t)maxM * D * es);
   w.max_probs = 2 * (4 * c.depth + 1);
   w.probs = (FcTnProblem*)bp.take(sizeof(FcTnProblem) * w.max_probs);
-  int maxN = 0;
-  for (int i = 0; i < 2; ++i) if (m->tw[i].present && w.t[i].N > maxN) maxN = w.t[i].N;
-  w.delta = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * maxN);
+  w.max_ln = 4 * c.depth;
+  w.lntab = (FcLnReduce*)bp.take(sizeof(FcLnReduce) * w.max_ln);
   w.loss_scratch = (float*)bp.take(sizeof(float) * (2 * (size_t)B * B + 2 * B + 64));
   w.bytes = bp.off;
   w.B = B; w.n_txt = n_txt;
@@ -322,6 +336,13 @@ struct Ctx {
   int dt;
   size_t es;
   std::vector<FcTnProblem>* defer = nullptr;   // non-null: weight/bias gradients are queued for the grouped launch
+  std::vector<FcLnReduce>* lnq = nullptr;      // non-null: LayerNorm dgamma/dbeta partials are queued likewise
+  int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res, void* dx, float* dg,
+             float* db, int M, int D, float* partial) const {
+    int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, lnq ? partial : nullptr);
+    if (r == 1) { lnq->push_back(FcLnReduce{partial, dg, db, fc_layernorm_bwd_partial_blocks(M), D}); return 0; }
+    return r;
+  }
   const void* W(int64_t off) const { return wc + (size_t)off * es; }
   // Y[M,N] = X[M,K] . W[N,K]^T
   int gemm_fwd(const void* X, const void* Wt, void* Y, int M, int N, int K, const GemmEpi& e) const {
@@ -439,6 +460,26 @@ static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int
   return 0;
 }
 
+static int ensure_side(const fc_model* m) {
+  if (!m->side) {
+    FC_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+  }
+  return 0;
+}
+static int fork_side(const fc_model* m, hipStream_t s) {
+  FC_TRY(ensure_side(m));
+  FC_CHECK_HIP(hipEventRecord(m->ev_fork, s));
+  FC_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+  return 0;
+}
+static int join_side(const fc_model* m, hipStream_t s) {
+  FC_CHECK_HIP(hipEventRecord(m->ev_join, m->side));
+  FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
+  return 0;
+}
+
 static int check_ws(const fc_model* m, int B, int n_txt, void* workspace, size_t bytes, Ws& w) {
   FC_REQUIRE(B > 0, "batch must be positive");
   FC_REQUIRE(workspace != nullptr, "workspace is null");
@@ -457,6 +498,16 @@ static int forward_impl(const fc_model* m, const float* params, const void* wc, 
   FC_TRY(check_ws(m, B, m->tw[1].present ? n_txt : 0, workspace, wbytes, w));
   w.feat_out = feat_out; w.droppath = droppath; w.ids = ids;
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
+  const bool both = m->tw[0].present && m->tw[1].present;
+  if (both) {   // text tower on the side stream, concurrently with the image tower
+    FC_TRY(fork_side(m, s));
+    Ctx c2 = c;
+    c2.s = m->side;
+    FC_TRY(tower_forward(c, w, 0, img, nullptr, feat_out, out_img));
+    FC_TRY(tower_forward(c2, w, 1, nullptr, ids, feat_out, out_txt));
+    FC_TRY(join_side(m, s));
+    return 0;
+  }
   if (m->tw[0].present) FC_TRY(tower_forward(c, w, 0, img, nullptr, feat_out, out_img));
   if (m->tw[1].present) FC_TRY(tower_forward(c, w, 1, nullptr, ids, feat_out, out_txt));
   return 0;
@@ -516,18 +567,19 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
     FC_TRY(linear_bwd_params(c, b.fc2, dm, L.gact, M, grads));
     { GemmEpi e; e.gelu_in = L.u; FC_TRY(c.gemm_dx(dm, c.W(b.fc2.w), L.gdu, M, D, Hd, e)); }                  // du = (dm.W2) * gelu'(u)
     FC_TRY(linear_bwd_params(c, b.fc1, L.gdu, L.h2, M, grads));
-    { GemmEpi e; FC_TRY(c.gemm_dx(L.gdu, c.W(b.fc1.w), w.dh, M, Hd, D, e)); }                                  // dh2
-    FC_TRY(fc_layernorm_bwd(c.dt, w.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, dx, L.gxmid, grads + b.n2w, grads + b.n2b, M, D, c.s));
+    const size_t lnp = (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D;
+    { GemmEpi e; FC_TRY(c.gemm_dx(L.gdu, c.W(b.fc1.w), t.dh, M, Hd, D, e)); }                                  // dh2
+    FC_TRY(c.ln_bwd(t.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, dx, L.gxmid, grads + b.n2w, grads + b.n2b, M, D, t.ln_partial + (2 * l + 1) * lnp));
     // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp)
     const float* s1 = dp_ptr(m, w.droppath, i, l, 0, B);
     const void* da = L.gxmid;
     if (s1) { FC_TRY(rowscale(c.dt, L.gxmid, L.gda, s1, N, M, D, c.s)); da = L.gda; }
     FC_TRY(linear_bwd_params(c, b.proj, da, L.o, M, grads));
-    { GemmEpi e; FC_TRY(c.gemm_dx(da, c.W(b.proj.w), w.dO, M, D, D, e)); }
-    FC_TRY(c.attn_bwd(L.qkv, L.o, w.dO, L.lse, w.delta, L.gdqkv, B, N));
+    { GemmEpi e; FC_TRY(c.gemm_dx(da, c.W(b.proj.w), t.dO, M, D, D, e)); }
+    FC_TRY(c.attn_bwd(L.qkv, L.o, t.dO, L.lse, t.delta, L.gdqkv, B, N));
     FC_TRY(linear_bwd_params(c, b.qkv, L.gdqkv, L.h1, M, grads));
-    { GemmEpi e; FC_TRY(c.gemm_dx(L.gdqkv, c.W(b.qkv.w), w.dh, M, 3 * D, D, e)); }                             // dh1
-    FC_TRY(fc_layernorm_bwd(c.dt, w.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, L.gxmid, t.gx[l], grads + b.n1w, grads + b.n1b, M, D, c.s));
+    { GemmEpi e; FC_TRY(c.gemm_dx(L.gdqkv, c.W(b.qkv.w), t.dh, M, 3 * D, D, e)); }                             // dh1
+    FC_TRY(c.ln_bwd(t.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, L.gxmid, t.gx[l], grads + b.n1w, grads + b.n1b, M, D, t.ln_partial + (2 * l) * lnp));
   }
   const void* dx = t.gx[0];
   if (i == 0) {
@@ -562,9 +614,33 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
                          Ws& w, hipStream_t s) {
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
   std::vector<FcTnProblem> probs;
+  std::vector<FcLnReduce> lnq;
   if (m->dt == FC_BF16) c.defer = &probs;   // all dW / db products of this backward go into one grouped MFMA launch
-  if (m->tw[0].present && d_out_img) FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
-  if (m->tw[1].present && d_out_txt) FC_TRY(tower_backward(c, w, 1, d_out_txt, grads));
+  c.lnq = &lnq;
+  const bool run0 = m->tw[0].present && d_out_img, run1 = m->tw[1].present && d_out_txt;
+  if (run0 && run1) {
+    FC_TRY(fork_side(m, s));
+    Ctx c2 = c;
+    c2.s = m->side;
+    FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
+    FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads));
+    FC_TRY(join_side(m, s));
+  } else {
+    if (run0) FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
+    if (run1) FC_TRY(tower_backward(c, w, 1, d_out_txt, grads));
+  }
+  if (!lnq.empty()) {
+    FC_REQUIRE((int)lnq.size() <= w.max_ln, "internal: too many queued LayerNorm reductions");
+    bool same = m->ln_dev == w.lntab && m->ln_host.size() == lnq.size() &&
+                memcmp(m->ln_host.data(), lnq.data(), lnq.size() * sizeof(FcLnReduce)) == 0;
+    if (!same) {
+      FC_CHECK_HIP(hipStreamSynchronize(s));
+      m->ln_host = lnq;
+      m->ln_dev = w.lntab;
+      FC_CHECK_HIP(hipMemcpyAsync(w.lntab, m->ln_host.data(), lnq.size() * sizeof(FcLnReduce), hipMemcpyHostToDevice, s));
+    }
+    FC_TRY(fc_ln_reduce_grouped(w.lntab, (int)lnq.size(), m->cfg.dim, s));
+  }
   if (!probs.empty()) {
     FC_REQUIRE((int)probs.size() <= w.max_probs, "internal: too many deferred weight-gradient problems");
     int tiles = 0;
