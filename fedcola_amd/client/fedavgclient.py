@@ -1,0 +1,211 @@
+"""``FedavgClient`` with the reference's surface (/root/reference/src/client/fedavgclient.py:15-190): same constructor,
+``download / update / upload / evaluate / __len__ / __repr__``, same ``update()`` result schema
+``{epoch: {'loss': sum(loss_b*|b|)/len(training_set), 'metrics': {...}}}``.
+
+What changed underneath: the batch-loop body (zero_grad, forward, criterion, backward, AdamW.step) is ONE call into
+libfedcola_hip (``fc_client_step``); weights, gradients and optimizer state live in flat device buffers for the whole round
+(no per-round H2D/D2H of the model, no per-step ``loss.item()`` sync: the loss sum is accumulated on the device and read
+once per epoch)."""
+from __future__ import annotations
+
+import copy
+import inspect
+import logging
+
+import torch
+
+from .. import _lib
+from .._lib import check, ptr
+from ..criterions import CRITERIA
+from ..utils import MetricManager
+from .baseclient import BaseClient
+
+logger = logging.getLogger(__name__)
+
+
+class FedavgClient(BaseClient):
+    def __init__(self, args, training_set, test_set, task="cls", eval_metrics=["acc1"], modality="ct", writer=None,
+                 criterion="CrossEntropyLoss"):
+        super().__init__()
+        self.args = args
+        self.training_set = training_set
+        self.test_set = test_set
+        self.optim = torch.optim.__dict__[self.args.optimizer]
+        self.criterion = CRITERIA[criterion] if criterion in CRITERIA else torch.nn.__dict__[criterion]
+        self.train_loader = self._create_dataloader(self.training_set, shuffle=not self.args.no_shuffle)
+        self.test_loader = self._create_dataloader(self.test_set, shuffle=False, test=True)
+        self.task = task
+        self.modality = modality
+        self.eval_metrics = eval_metrics
+        self.writer = writer
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.dataset = None
+
+    def _refine_optim_args(self, args):
+        """fedavgclient.py:34-42: optimizer kwargs = the optimizer's named args that ``args`` defines."""
+        required_args = inspect.getfullargspec(self.optim)[0]
+        return {a: getattr(args, a) for a in required_args if hasattr(args, a)}
+
+    def _create_dataloader(self, dataset, shuffle, test=True):
+        if self.args.B == 0:
+            self.args.B = len(self.training_set)
+        return torch.utils.data.DataLoader(dataset=dataset, batch_size=self.args.B, shuffle=shuffle)
+
+    # ------------------------------------------------------------------ the hot loop (fedavgclient.py:55-116)
+    def update(self):
+        mm = MetricManager(self.eval_metrics) if self.modality != "img+txt" else MetricManager([])
+        model = self.model
+        model.train()
+        model.to(self.device)
+        oargs = self._refine_optim_args(self.args)
+        fused = self.args.optimizer == "AdamW" and getattr(self.args, "max_grad_norm", 0) <= 0 and \
+            not getattr(self.args, "distributed", False) and not getattr(self.args, "mm_distributed", False)
+        if not fused:
+            return self._update_unfused(mm, oargs)
+        dev = model.flat.device
+        n = model.flat.numel()
+        grads = torch.zeros(n, device=dev)
+        exp_avg = torch.zeros(n, device=dev)        # optimizer re-created every round: fresh state (fedavgclient.py:63)
+        exp_avg_sq = torch.zeros(n, device=dev)
+        lossbuf = torch.zeros(2, device=dev)
+        lr = float(oargs.get("lr", 1e-3))
+        betas = oargs.get("betas", (0.9, 0.999))
+        eps = float(oargs.get("eps", 1e-8))
+        wd = float(oargs.get("weight_decay", 1e-2))
+        L = _lib.lib()
+        step = 0
+        for e in range(self.args.E):
+            num = 0
+            lossbuf.zero_()
+            broke = False
+            for batch in self.train_loader:
+                if num >= 2 and self.args.debug:                       # fedavgclient.py:73-75
+                    mm.add_loss_sum(lossbuf[0].clone())
+                    mm.aggregate(num * self.args.B, e + 1)
+                    broke = True
+                    break
+                if self.modality == "img+txt":
+                    inputs, targets = batch[0], batch[1]
+                    img = inputs.to(dev, non_blocking=True).contiguous().float()
+                    ids = targets.to(dev, non_blocking=True).contiguous().long()
+                    labels = None
+                elif self.modality == "img":
+                    img = batch[0].to(dev, non_blocking=True).contiguous().float()
+                    if img.dim() == 4 and img.shape[1] == 1:
+                        img = img.repeat(1, 3, 1, 1)
+                    ids, labels = None, batch[1].to(dev, non_blocking=True).contiguous().long()
+                else:
+                    ids = batch[0].to(dev, non_blocking=True).contiguous().long()
+                    img, labels = None, batch[1].to(dev, non_blocking=True).contiguous().long()
+                B = (img if img is not None else ids).shape[0]
+                n_txt = ids.shape[1] if ids is not None else 0
+                model.prepare_weights()
+                ws = model.workspace(B, n_txt)
+                dp = model.make_droppath(B)
+                step += 1
+                check(L.fc_client_step(model._handle.h, ptr(model.flat), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(model._wc_or_flat()),
+                                       ptr(img), ptr(ids), ptr(labels), B, n_txt, ptr(dp), lr, float(betas[0]), float(betas[1]), eps, wd,
+                                       step, ptr(lossbuf), ptr(ws), ws.numel(), _lib.stream_ptr()))
+                model._wc_version = model.flat._version          # fc_client_step refreshed the compute weights itself
+                if mm.metric_funcs:                                    # acc1 etc. for uni-modal clients
+                    i = 0 if self.modality == "img" else 1
+                    logits = torch.empty(B, model.num_classes[i], device=dev)
+                    check(L.fc_copy_outputs(model._handle.h, ptr(ws), ws.numel(), ptr(logits) if i == 0 else None,
+                                            ptr(logits) if i == 1 else None, _lib.stream_ptr()))
+                    for module in mm.metric_funcs.values():
+                        module.collect(logits, labels)
+                num += 1
+            if not broke:
+                mm.add_loss_sum(lossbuf[0].clone())                    # sum_b loss_b*|b| accumulated on the device
+                mm.aggregate(len(self.training_set), e + 1)
+                res = mm.results[e + 1]
+                logger.info(f'[Client {self.id}] loss: {res["loss"]}')
+        # the reference moves the model back to the CPU here (fedavgclient.py:114); weights stay resident in HBM instead
+        return mm.results
+
+    def _update_unfused(self, mm, oargs):
+        """Any torch optimizer / gradient clipping: HIP forward+backward through autograd, torch.optim on the flat views."""
+        model = self.model
+        dev = model.flat.device
+        optimizer = self.optim(model.parameters(), **oargs)
+        for e in range(self.args.E):
+            num = 0
+            broke = False
+            for batch in self.train_loader:
+                if num >= 2 and self.args.debug:
+                    mm.aggregate(num * self.args.B, e + 1)
+                    broke = True
+                    break
+                model.flat.grad = None
+                if self.modality == "img+txt":
+                    inputs, targets = batch[0].to(dev), batch[1].to(dev)
+                    outputs = model([inputs, targets], feat_out=True)
+                    loss = self.criterion()(*outputs)
+                elif self.modality == "img":
+                    inputs, targets = batch[0].to(dev), batch[1].to(dev)
+                    outputs = model([inputs, None])[0]
+                    loss = self.criterion()(outputs, targets)
+                else:
+                    inputs, targets = batch[0].to(dev), batch[1].to(dev)
+                    outputs = model([None, inputs])[1]
+                    loss = self.criterion()(outputs, targets)
+                loss.backward()
+                params = list(model.parameters())                      # refreshes the .grad views
+                if getattr(self.args, "max_grad_norm", 0) > 0:
+                    torch.nn.utils.clip_grad_norm_([model.flat], self.args.max_grad_norm)
+                optimizer.step()
+                model._bump()
+                if self.modality != "img+txt":
+                    mm.track(loss.item(), outputs.detach(), targets)
+                else:
+                    mm.track(loss.item(), outputs[0].detach())
+                num += 1
+            if not broke:
+                mm.aggregate(len(self.training_set), e + 1)
+        return mm.results
+
+    @torch.inference_mode()
+    def evaluate(self):
+        """fedavgclient.py:118-153 ("Not used" in the reference)."""
+        if self.args.train_only:
+            return {"loss": -1, "metrics": {"none": -1}}
+        mm = MetricManager(self.eval_metrics)
+        self.model.eval()
+        self.model.to(self.device)
+        for inputs, targets in self.test_loader:
+            inputs, targets = inputs.to(self.device), targets.to(self.device)
+            x = [inputs, None] if self.modality == "img" else [None, inputs]
+            outputs = self.model(x)[0 if self.modality == "img" else 1]
+            loss = self.criterion()(outputs, targets)
+            mm.track(loss.item(), outputs, targets)
+        mm.aggregate(len(self.test_set))
+        return mm.results
+
+    def download(self, models):
+        """fedavgclient.py:155-156 (a device-to-device clone of the flat buffer)."""
+        self.model = copy.deepcopy(models[self.dataset])
+
+    def upload(self):
+        """fedavgclient.py:158-184.  Returns the state_dict (device tensors); with ``with_aux`` on a uni-modal client every
+        re-param linear's weight is folded (W + A*s, ``fc_upload_fold``) and the aux / scale keys are dropped."""
+        model = self.model
+        sd = model.state_dict()
+        if self.args.with_aux and self.modality != "img+txt":
+            if self.args.aux_attn_only and self.args.aux_mlp_only:
+                raise ValueError("Both aux_attn_only and aux_mlp_only cannot be True.")
+            folded = torch.empty_like(model.flat.data)
+            check(_lib.lib().fc_upload_fold(model._handle.h, ptr(model.flat), ptr(folded), _lib.stream_ptr()))
+            self._folded = folded                                       # keep alive: the views below alias it
+            new_sd = {}
+            for k, s in model.segments.items():
+                if "aux" in k or "cross_modal_scale" in k:
+                    continue
+                new_sd[k] = folded[s["offset"]: s["offset"] + s["numel"]].view(s["shape"])
+            return new_sd
+        return sd
+
+    def __len__(self):
+        return len(self.training_set)
+
+    def __repr__(self):
+        return f"CLIENT < {self.id} >"

@@ -680,25 +680,26 @@ int fc_colsum(int dt, const void* dy, float* db, int M, int N, int accumulate, h
 }
 
 // ======================================================================== aggregation blend (fedavgserver.py:656-664 closed form; K14)
-__global__ void __launch_bounds__(256) k_blend(float* __restrict__ out, const float* __restrict__ g, const float* const* __restrict__ thetas, int m,
+__global__ void __launch_bounds__(256) k_blend(float* __restrict__ out, const float* __restrict__ g, const float* const* __restrict__ bases, int m,
                                                const int64_t* __restrict__ seg_off, const int64_t* __restrict__ seg_len,
-                                               const float* __restrict__ seg_w) {
+                                               const int64_t* __restrict__ src_off, const float* __restrict__ seg_w) {
   int sgi = blockIdx.y;
   int64_t off = seg_off[sgi], len = seg_len[sgi];
   const float* w = seg_w + (size_t)sgi * (m + 1);
+  const int64_t* so = src_off + (size_t)sgi * m;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
-    float acc = w[0] * g[off + i];
+    float acc = w[0] != 0.f ? w[0] * g[off + i] : 0.f;
     for (int j = 0; j < m; ++j) {
       float wj = w[1 + j];
-      if (wj != 0.f) acc += wj * thetas[j][off + i];
+      if (wj != 0.f && so[j] >= 0) acc += wj * bases[j][so[j] + i];
     }
     out[off + i] = acc;
   }
 }
-int fc_blend_segments(float* out, const float* g, const float* const* thetas, int m, const int64_t* seg_off, const int64_t* seg_len,
-                      const float* seg_w, int nseg, hipStream_t s) {
+int fc_blend_segments(float* out, const float* g, const float* const* bases, int m, const int64_t* seg_off, const int64_t* seg_len,
+                      const int64_t* src_off, const float* seg_w, int nseg, hipStream_t s) {
   if (nseg <= 0) return 0;
-  hipLaunchKernelGGL(k_blend, dim3(64, nseg), dim3(256), 0, s, out, g, thetas, m, seg_off, seg_len, seg_w);
+  hipLaunchKernelGGL(k_blend, dim3(64, nseg), dim3(256), 0, s, out, g, bases, m, seg_off, seg_len, src_off, seg_w);
   FC_LAUNCH_CHECK();
   return 0;
 }

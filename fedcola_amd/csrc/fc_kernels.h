@@ -64,11 +64,10 @@ int fc_reparam_grad(const float* gW, const float* A, const float* scale, float* 
 // ---- column sum (bias grads): db[n] (+)= sum_m dy[m,n]
 int fc_colsum(int dt, const void* dy, float* db, int M, int N, int accumulate, hipStream_t s);
 
-// ---- aggregation (K14): out[i] = wg*g[i] + sum_j w[j]*theta_j[i] over a segment table (host-computed weights)
-// seg table on device: for each segment s: offset, numel, then weights  wg, w[0..m)
-int fc_blend_segments(float* out, const float* g, const float* const* thetas /* device array of m ptrs */, int m,
-                      const int64_t* seg_off, const int64_t* seg_len, const float* seg_w /* [nseg, m+1] */, int nseg,
-                      hipStream_t s);
+// ---- aggregation (K14): out[seg] = w[seg][0]*g[seg] + sum_j w[seg][1+j] * (bases[j] + src_off[seg][j])[0..len)
+// (host-computed closed-form weights; src_off < 0: client j does not hold that key).  All tables are device arrays.
+int fc_blend_segments(float* out, const float* g, const float* const* bases, int m, const int64_t* seg_off, const int64_t* seg_len,
+                      const int64_t* src_off, const float* seg_w, int nseg, hipStream_t s);
 int fc_scale_segments_impl(float* buf, const int64_t* seg_off, const int64_t* seg_len, const float* seg_w, int nseg, hipStream_t s);
 
 // ---- generic strided GEMM (any shape; fp32 accumulate).  C[m,n] = epi( sum_k A(m,k)*B(k,n) )

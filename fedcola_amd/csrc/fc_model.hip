@@ -740,9 +740,25 @@ extern "C" int fc_client_step(const fc_model_t* m, float* params, float* grads, 
 }
 
 // ---------------------------------------------------------------- aggregation
-extern "C" int fc_aggregate_blend(float* out, const float* global, const float* const* thetas, int32_t n_clients, const int64_t* seg_offset,
-                                  const int64_t* seg_numel, const float* seg_weights, int32_t n_segments, void* stream) {
-  return fc_blend_segments(out, global, thetas, n_clients, seg_offset, seg_numel, seg_weights, n_segments, (hipStream_t)stream);
+extern "C" int fc_aggregate_blend(float* out, const float* global, const float* const* client_bases, int32_t n_clients,
+                                  const int64_t* seg_offset, const int64_t* seg_numel, const int64_t* src_offset, const float* seg_weights,
+                                  int32_t n_segments, void* stream) {
+  return fc_blend_segments(out, global, client_bases, n_clients, seg_offset, seg_numel, src_offset, seg_weights, n_segments, (hipStream_t)stream);
+}
+// copy of the last forward's head outputs (logits / features) out of the workspace: metric tracking in FedavgClient.update
+extern "C" int fc_copy_outputs(const fc_model_t* m, void* workspace, size_t workspace_bytes, float* out_img, float* out_txt, void* stream) {
+  FC_REQUIRE(m->last.ws == workspace && workspace, "fc_copy_outputs: no forward on this workspace");
+  Ws w;
+  FC_TRY(check_ws(m, m->last.B, m->last.n_txt, workspace, workspace_bytes, w));
+  float* outs[2] = {out_img, out_txt};
+  for (int i = 0; i < 2; ++i) {
+    if (!m->tw[i].present || !outs[i]) continue;
+    bool normalize = m->last.feat_out || m->tw[i].task == FC_TASK_RTV;
+    const float* src = normalize ? w.t[i].out : w.t[i].logits;
+    size_t width = normalize ? (size_t)m->cfg.dim : (size_t)m->tw[i].ncls;
+    FC_CHECK_HIP(hipMemcpyAsync(outs[i], src, sizeof(float) * m->last.B * width, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  }
+  return 0;
 }
 extern "C" int fc_scale_segments(float* buf, const int64_t* seg_offset, const int64_t* seg_numel, const float* seg_weight, int32_t n_segments,
                                  void* stream) {

@@ -100,11 +100,16 @@ int fc_client_step(const fc_model_t* m, float* params, float* grads, float* exp_
                    const float* droppath, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float* lossbuf, void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- FedavgServer._aggregate blend (fedavgserver.py:656-664) in closed form:
- * out[seg] = w[seg][0]*global[seg] + sum_j w[seg][1+j]*thetas[j][seg].  All arrays are device memory. */
-int fc_aggregate_blend(float* out, const float* global, const float* const* thetas, int32_t n_clients,
-                       const int64_t* seg_offset, const int64_t* seg_numel, const float* seg_weights, int32_t n_segments,
-                       void* stream);
+/* ---- FedavgServer._aggregate blend (fedavgserver.py:656-664) in closed form, per state_dict key (segment):
+ * out[seg_offset[s] + i] = w[s][0]*global[seg_offset[s] + i] + sum_j w[s][1+j] * client_bases[j][src_offset[s][j] + i].
+ * Clients of other datasets hold the key at another offset of their own flat buffer (src_offset, < 0: key absent).
+ * seg_weights is [n_segments, n_clients+1]; every table is device memory. */
+int fc_aggregate_blend(float* out, const float* global, const float* const* client_bases, int32_t n_clients,
+                       const int64_t* seg_offset, const int64_t* seg_numel, const int64_t* src_offset, const float* seg_weights,
+                       int32_t n_segments, void* stream);
+/* outputs of the last forward on this workspace (logits of 'cls' towers / unit-norm features), for metric tracking
+ * (mm.track(loss, outputs, targets), fedavgclient.py:102) */
+int fc_copy_outputs(const fc_model_t* m, void* workspace, size_t workspace_bytes, float* out_img, float* out_txt, void* stream);
 /* in-place per-segment scaling (pre-weighting before an RCCL all-reduce(sum)) */
 int fc_scale_segments(float* buf, const int64_t* seg_offset, const int64_t* seg_numel, const float* seg_weight,
                       int32_t n_segments, void* stream);

@@ -1,0 +1,64 @@
+"""world_size-2 CPU (gloo) test of the distributed aggregation path: each rank owns the sampled clients at positions
+p % world == rank, forms its local partial (CPU stand-in for the HIP blend), one all-reduce sums the partials, and every
+rank must end with the reference's sequentially blended global models (golden agg.json)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, idx, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    import golden_util as G
+    import host_util as H
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rec = G.load("agg.json")[idx]
+        srv = H.make_server(rec)
+        # drop the models of clients this rank does not own (they were "trained on another GPU")
+        for pos, i in enumerate(rec["ids"]):
+            if srv._owner_rank(pos, world) != rank:
+                srv.clients[i].model = None
+        for c in srv.clients:
+            if c.id not in rec["ids"]:
+                c.model = None
+        H.run_aggregation(srv, rec, local_partial=H.cpu_local_partial)
+        H.check_aggregation(srv, rec, tol=3e-6)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("idx", [0, 1, 4])
+def test_two_rank_aggregation_matches_reference(idx):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, idx, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

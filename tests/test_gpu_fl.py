@@ -1,0 +1,157 @@
+"""GPU tests of the federated plugin surface: FedavgClient.update (fused HIP step), upload fold, device aggregation, one full
+FedavgServer round -- against the golden vectors produced by the reference and against the oracle."""
+import copy
+
+import pytest
+import torch
+
+import golden_util as G
+import host_util as H
+from oracle import aggregate_oracle as AO
+from refstub import RefArgs
+from synth import det_ids, det_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+class SynthPairs(torch.utils.data.Dataset):
+    def __init__(self, n, seq, vocab):
+        self.img = det_tensor((n, 3, 224, 224), 2000, 0.5)
+        self.ids = det_ids((n, seq), 11, vocab)
+
+    def __len__(self):
+        return self.img.shape[0]
+
+    def __getitem__(self, i):
+        return self.img[i], self.ids[i], i // 5, i, i
+
+
+class SynthCls(torch.utils.data.Dataset):
+    def __init__(self, n, kind, classes, seq=8, vocab=30, seed=0):
+        self.x = det_tensor((n, 3, 224, 224), 3000 + seed, 0.5) if kind == "img" else det_ids((n, seq), 13 + seed, vocab)
+        self.y = (torch.arange(n) * 7 + seed) % classes
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return self.x[i], self.y[i]
+
+
+def toy_model(precision="fp32"):
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    mk = G.load("model_toy.json")["mk"]
+    m = M(precision=precision, init=False, **mk)
+    m.load_state_dict(G.case_weights("toy"))
+    return m.cuda()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_client_update_matches_reference_result_dict(fused):
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    rec = G.load("update_toy.json")
+    args = RefArgs(E=rec["E"], B=rec["B"], lr=rec["lr"], optimizer="AdamW", no_shuffle=True, max_grad_norm=0.0 if fused else 1e9)
+    ds = SynthPairs(rec["n"], 8, 30)
+    cl = FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cuda"
+    cl.download({"Flickr30k": toy_model()})
+    res = cl.update()
+    assert set(res.keys()) == {1, 2}
+    for e in (1, 2):
+        assert abs(res[e]["loss"] - rec["results"][str(e)]["loss"]) <= 3e-4, (e, res[e], rec["results"][str(e)])
+        assert res[e]["metrics"] == {}
+    sd = cl.upload()
+    for k, r in rec["after"].items():
+        # 6 AdamW steps of lr 1e-3 on the toy model: compare loosely (sign-sensitive near-zero gradients, see golden_util)
+        exp = torch.tensor(r["full"]).reshape(r["shape"])
+        err = (sd[k].cpu() - exp).abs()
+        if k.endswith("attn.qkv.bias"):
+            # the key bias has an exactly-zero true gradient (softmax is shift invariant): Adam turns its round-off noise
+            # into +-lr steps, so those D entries are not comparable between any two implementations
+            D = exp.numel() // 3
+            err[D:2 * D] = 0
+        assert err.max() <= 2.5e-3, k
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_device_aggregation_vs_golden(idx):
+    rec = G.load("agg.json")[idx]
+    srv = H.make_server(rec, device="cuda")
+    H.run_aggregation(srv, rec)                    # default: fc_aggregate_blend on the device (+ fc_upload_fold for aux clients)
+    H.check_aggregation(srv, rec, tol=3e-6)
+
+
+def test_full_round_mixed_clients_smoke_and_parity():
+    """One FedavgServer.update() round on toy-width models with mixed img / txt / img+txt clients (FedCola setting:
+    shared_param=attn, share_scope=modality, compensation, with_aux): runs the fused HIP client steps, the device aggregation
+    and the aux refresh; the aggregation result is re-derived with the oracle's sequential blend from the clients' uploads."""
+    from fedcola_amd.server.fedavgserver import FedavgServer
+    from fedcola_amd.utils import set_seed
+    set_seed(3)
+    args = RefArgs(shared_param="attn", share_scope="modality", compensation=True, with_aux=True, aux_trained=True,
+                   datasets=["CIFAR100", "AG_NEWS", "Flickr30k", "Coco"], modalities=["img", "txt", "img+txt", "img+txt"],
+                   out_modality_scales=[1, 1, 1], E=1, B=4, lr=1e-3, model_name="mome_toy_patch16_224", seq_len=8, Cs=[0.5], K=6,
+                   equal_sampled=True, eval_type="local", result_path="/tmp/fc_test_results", exp_name="t", vocab_size=30)
+    cds = []
+    for i in range(2):
+        d = SynthCls(8, "img", 100, seed=i)
+        cds.append((d, d, "cls", "img", "CIFAR100"))
+    for i in range(2):
+        d = SynthCls(8, "txt", 4, vocab=30000, seed=i)
+        cds.append((d, d, "cls", "txt", "AG_NEWS"))
+    for i in range(2):
+        d = SynthPairs(8, 8, 7732)
+        cds.append((d, d, "rtv", "img+txt", "Flickr30k"))
+    srv = FedavgServer(args, None, None, cds, "mome_toy_patch16_224")
+    assert list(srv.global_models.keys()) == ["CIFAR100", "AG_NEWS", "Flickr30k"]
+    before = {ds: {k: v.clone() for k, v in m.state_dict().items()} for ds, m in srv.global_models.items()}
+    srv.round = 1
+    # run the round but keep the clients' models for the oracle cross-check
+    ids = srv._sample_clients()
+    sizes = srv._request(ids, eval=False)
+    assert set(sizes.keys()) == set(ids) and len(ids) == 3
+    layers = ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
+    uploads = {}
+    for i in ids:
+        c = srv.clients[i]
+        sd = {k: v.detach().cpu().clone() for k, v in c.model.state_dict().items()}
+        uploads[i] = AO.upload_fold(sd, layers) if c.modality != "img+txt" else sd
+    infos = {c.id: AO.ClientInfo(c.dataset, c.task, c.modality) for c in srv.clients}
+    from fedcola_amd.server.fedavgserver import DATASET_2_MODALITY, DATASET_2_TASK
+    for n, ds in enumerate(srv.global_models):
+        srv.global_model = srv.global_models[ds]
+        srv.task, srv.modality, srv.dataset = DATASET_2_TASK[ds], DATASET_2_MODALITY[ds], ds
+        srv.out_modality_scale = args.out_modality_scales[n]
+        srv._aggregate(ids, sizes)
+        g = {k: before[ds][k].cpu() for k in srv.global_model.required_params().keys()}
+        coef = AO.coefficients(list(g.keys()), srv.param_scope, ids, sizes, infos, dataset=ds, task=srv.task, modality=srv.modality,
+                               out_modality_scale=1, compensation=True, share_scope="modality", arg_modalities=args.modalities)
+        exp = AO.sequential_blend(g, uploads, ids, coef)
+        sd = srv.global_model.state_dict()
+        for k, v in exp.items():
+            assert (sd[k].cpu() - v).abs().max() <= 3e-6 * max(1.0, float(v.abs().max())), (ds, k)
+    srv.finalize()
+    ck = torch.load("/tmp/fc_test_results/t/Flickr30k.pt")
+    assert list(ck.keys()) == list(srv.global_models["Flickr30k"].state_dict().keys())
+
+
+def test_plumbing_config0_two_img_clients_fedavg():
+    """BASELINE config[0]: Flickr30k-free FedAvg plumbing, 2 img-only clients, ViT-Tiny, 1 local epoch (full update() rounds)."""
+    from fedcola_amd.server.fedavgserver import FedavgServer
+    from fedcola_amd.utils import set_seed
+    set_seed(1)
+    args = RefArgs(shared_param="none", share_scope="dataset", datasets=["CIFAR100", "Coco"], modalities=["img", "img+txt"],
+                   out_modality_scales=[1], E=1, B=4, lr=1e-4, seq_len=8, Cs=[1.0], K=2, equal_sampled=True, eval_type="local",
+                   dropout=0.1)
+    cds = [(SynthCls(8, "img", 100, seed=i),) * 2 + ("cls", "img", "CIFAR100") for i in range(2)]
+    srv = FedavgServer(args, None, None, cds, "mome_tiny_patch16")
+    w0 = srv.global_models["CIFAR100"].flat.data.clone()
+    for r in range(2):
+        srv.round = r + 1
+        ids = srv.update()
+        assert ids == [0, 1]
+    res = srv.results[2]["clients_updated"]
+    assert set(res.keys()) == {"0", "1"} and all(1 in v and "acc1" in v[1]["metrics"] for v in res.values())
+    assert torch.isfinite(srv.global_models["CIFAR100"].flat.data).all()
+    assert (srv.global_models["CIFAR100"].flat.data - w0).abs().max() > 0
+    assert abs(srv.curr_lr - 1e-4 * 0.99 ** 2) < 1e-12
