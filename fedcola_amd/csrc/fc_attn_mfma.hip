@@ -41,10 +41,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* T, int r0, int cb, int lan
   return f;
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
-  bf16x8 f;
-  f[0] = (short)f2bf(a[0]); f[1] = (short)f2bf(a[1]); f[2] = (short)f2bf(a[2]); f[3] = (short)f2bf(a[3]);
-  f[4] = (short)f2bf(b[0]); f[5] = (short)f2bf(b[1]); f[6] = (short)f2bf(b[2]); f[7] = (short)f2bf(b[3]);
-  return f;
+  uint4 u = make_uint4(f2bf2(a[0], a[1]), f2bf2(a[2], a[3]), f2bf2(b[0], b[1]), f2bf2(b[2], b[3]));
+  return *(bf16x8*)&u;
 }
 // stage a [N][64] slice (row stride ld elements) into a swizzled LDS tile of npad rows (zero rows past N)
 __device__ __forceinline__ void stage_tile(char* T, const bf16_t* __restrict__ src, long ld, int N, int npad, int tid) {

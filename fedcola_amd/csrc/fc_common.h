@@ -41,11 +41,22 @@ __host__ __device__ inline float bf2f(bf16_t u) {
   return c.f;
 }
 __host__ __device__ inline bf16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __bf16 h = (__bf16)f;                     // v_cvt_pk_bf16_f32 on gfx950: round-to-nearest-even, NaN stays NaN
+  return *(bf16_t*)&h;
+#else
   union { uint32_t i; float f; } c;
   c.f = f;
   uint32_t u = c.i;
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // keep NaN a NaN
   return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);                // round to nearest even
+#endif
+}
+// two floats -> packed bf16x2 (one v_cvt_pk_bf16_f32)
+__device__ inline uint32_t f2bf2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v = {(__bf16)lo, (__bf16)hi};
+  return *(uint32_t*)&v;
 }
 
 template <typename T> struct Io;
@@ -75,6 +86,21 @@ __device__ inline float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * __expf(-0.5f * x * x) * 0.39894228040143267794f;
 }
 
+// erf-GELU with the Abramowitz-Stegun 7.1.26 rational form of erf (|error| <= 1.5e-7, far below bf16 resolution): one
+// v_exp + one v_rcp + a few FMAs instead of libm's erff (~40 VALU ops).  Used by the bf16 MFMA epilogues only; the fp32
+// parity path keeps erff.
+__device__ inline void gelu_fast_parts(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float ex = __expf(-z * z);                          // = exp(-x^2/2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfz = 1.0f - poly * ex;                     // erf(|x|/sqrt 2)
+  cdf = 0.5f * (1.0f + copysignf(erfz, x));
+  pdf = ex * 0.39894228040143267794f;
+}
+__device__ inline float gelu_fast(float x) { float c, p; gelu_fast_parts(x, c, p); return x * c; }
+__device__ inline float gelu_fast_grad(float x) { float c, p; gelu_fast_parts(x, c, p); return c + x * p; }
+
 static inline int fc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- GEMM epilogue description (shared by generic + MFMA GEMMs)
@@ -90,5 +116,6 @@ struct GemmEpi {
   float alpha = 1.0f;               // result = alpha*acc (+bias...)
   int patch_rows = 0;               // >0: patch-embed remap: out row = m + m/patch_rows + 1, adds pos[1 + m%patch_rows]
   const float* pos = nullptr;       // [1+patch_rows, N] fp32
+  long long* stamps = nullptr;      // development: per-workgroup s_memtime stamps [grid][32]
   int dbg = 0;                      // development ablations (FC_GEMM_DBG): 1 = no global loads in the loop, 2 = no epilogue, 4 = no MFMA
 };

@@ -45,11 +45,7 @@ template <> struct V8<bf16_t> {
     for (int i = 0; i < 8; ++i) v[i] = bf2f(h[i]);
   }
   static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
-    uint4 u;
-    bf16_t* h = (bf16_t*)&u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = f2bf(v[i]);
-    *(uint4*)p = u;
+    *(uint4*)p = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
   }
 };
 #define LNV_MAXC 2  // chunks of 8 per lane: D <= 64*8*2

@@ -22,6 +22,14 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
+// (__syncthreads() carries a release fence: with stores or loads in flight hipcc drains vmcnt(0) in front of every
+// barrier, which serialises the register prefetch pipeline and makes each epilogue wait out its own HBM write latency.)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 #define BM 128
 #define BN 128
 #define BK 64
@@ -46,6 +54,21 @@ struct Operand {
   int c8;             // KC only: first k of this lane's 16-B chunk inside a tile
 };
 #define FC_OOB 0x80000000u
+template <int MODE>
+__device__ __forceinline__ void retarget_operand(Operand& o, long ld, int row0, int nrows, int tid, bool valid) {
+  // move the per-lane offsets to another tile of the same matrix (row0 = first row (KC) / first column (KR))
+  if (MODE == KC) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int r = row0 + (tid >> 3) + 32 * p;
+      o.voff[p] = (valid && r < nrows) ? (unsigned)((r * ld + o.c8) * 2) : FC_OOB;
+    }
+  } else {
+    int col = row0 + (tid & 15) * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o.voff[p] = (valid && col < nrows) ? (unsigned)((((tid >> 4) + 16 * p) * ld + col) * 2) : FC_OOB;
+  }
+}
 template <int MODE>
 __device__ __forceinline__ Operand make_operand(const bf16_t* P, long ld, int row0, int nrows, int K, int tid) {
   Operand o;
@@ -128,11 +151,7 @@ template <> struct Vec8<bf16_t> {
     for (int i = 0; i < 8; ++i) v[i] = bf2f(h[i]);
   }
   static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
-    uint4 u;
-    bf16_t* h = (bf16_t*)&u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = f2bf(v[i]);
-    *(uint4*)p = u;
+    *(uint4*)p = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
   }
 };
 template <> struct Vec8<float> {
@@ -208,6 +227,89 @@ __device__ __forceinline__ void acc_to_lds(float* Cs, const f32x4 (&acc)[4][4], 
 
 
 
+// LDS image -> global with the fused epilogue.  The epilogue KIND is a compile-time parameter: every load it needs is
+// unconditional (rows past M are clamped for the loads and masked for the stores), so hipcc can issue the whole batch and
+// use counted waits.  (With run-time option flags each optional load sat in its own basic block behind an
+// s_waitcnt vmcnt(0), which also drained the register prefetch pipeline: 17k cycles per tile instead of ~2k.)
+enum { EPI_PLAIN = 0, EPI_BIAS, EPI_RES, EPI_RES_SCALE, EPI_GELU, EPI_GELU_GRAD, EPI_PATCH, EPI_GENERIC };
+
+template <int EPI, typename TC>
+__device__ __forceinline__ void tile_epilogue(const float* Cs, TC* C, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid) {
+  const int c8 = (tid & 15) * 8, n = n0 + c8, r0 = tid >> 4;
+  if (EPI == EPI_GENERIC) {
+    if (n >= N) return;
+#pragma unroll 1
+    for (int p = 0; p < 8; ++p) {
+      int row = r0 + 16 * p, m = m0 + row;
+      if (m < M) {
+        float v[8];
+        float4 x0 = *(const float4*)(Cs + row * CS_LD + c8), x1 = *(const float4*)(Cs + row * CS_LD + c8 + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        epi_store8<TC>(C, ldc, m, n, v, e, N);
+      }
+    }
+    return;
+  }
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_PATCH;
+  constexpr bool HAS_RES = EPI == EPI_RES || EPI == EPI_RES_SCALE;
+  const int nc = n < N ? n : N - 8;                     // clamped column for the loads
+  float bias[8];
+  if (HAS_BIAS) Vec8<float>::ld(e.bias + nc, bias);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float rin[4][8], rpos[4][8], sc[4];
+    size_t off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                         // request every input of the batch first
+      const int m = m0 + r0 + 16 * (half * 4 + q);
+      const int mc = m < M ? m : M - 1;
+      long orow = mc;
+      if (EPI == EPI_PATCH) orow = (long)mc + mc / e.patch_rows + 1;
+      off[q] = (size_t)orow * ldc + nc;
+      if (HAS_RES) Vec8<TC>::ld((const TC*)e.res + off[q], rin[q]);
+      if (EPI == EPI_GELU_GRAD) Vec8<TC>::ld((const TC*)e.gelu_in + off[q], rin[q]);
+      if (EPI == EPI_PATCH) Vec8<float>::ld(e.pos + (size_t)(1 + mc % e.patch_rows) * N + nc, rpos[q]);
+      if (EPI == EPI_RES_SCALE) sc[q] = e.rowscale[mc / e.rows_per_sample];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = r0 + 16 * (half * 4 + q);
+      float v[8];
+      float4 x0 = *(const float4*)(Cs + row * CS_LD + c8), x1 = *(const float4*)(Cs + row * CS_LD + c8 + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+      if (HAS_BIAS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += bias[i];
+      }
+      if (EPI == EPI_PATCH) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += rpos[q][i];
+      }
+      const bool ok = (m0 + row < M) && (n < N);
+      if (EPI == EPI_GELU) {
+        if (ok) Vec8<TC>::st((TC*)e.preact + off[q], v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_fast(v[i]);
+      }
+      if (EPI == EPI_GELU_GRAD) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= gelu_fast_grad(rin[q][i]);
+      }
+      if (EPI == EPI_RES_SCALE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= sc[q];
+      }
+      if (HAS_RES) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += rin[q][i];
+      }
+      if (ok) Vec8<TC>::st(C + off[q], v);
+    }
+  }
+}
+
 // ---- main loop shared by the single-problem and the grouped kernels.
 // Operands are swapped in the MFMA (D' = B.A^T) so that acc[i][j][x] = C[m = 16i + lane&15][n = 16j + 4(lane>>4) + x]:
 // a lane then owns 4 consecutive output columns and the epilogue needs no LDS round trip.
@@ -265,16 +367,16 @@ __device__ __forceinline__ void gemm_mainloop(const bf16_t* __restrict__ A, long
   tile_load<AMODE, BMODE>(R0, oa, ob, 0, K);
   tile_load<AMODE, BMODE>(R1, oa, ob, BK, K);
   tile_store<AMODE, BMODE, COLSUM>(R0, buf0, tid, cs, do_colsum);
-  __syncthreads();
+  lds_barrier();
   for (int t = 0; t < T; t += 2) {
     if (!(dbg & 1)) tile_load<AMODE, BMODE>(R0, oa, ob, (t + 2) * BK, K);
     if (!(dbg & 4)) tile_compute<AMODE, BMODE>(buf0, acc, wm, wn, lane);
     tile_store<AMODE, BMODE, COLSUM>(R1, buf1, tid, cs, do_colsum);
-    __syncthreads();
+    lds_barrier();
     if (!(dbg & 1)) tile_load<AMODE, BMODE>(R1, oa, ob, (t + 3) * BK, K);
     if (!(dbg & 4)) tile_compute<AMODE, BMODE>(buf1, acc, wm, wn, lane);   // an odd T ends on an all-zero tile: adds nothing
     tile_store<AMODE, BMODE, COLSUM>(R0, buf0, tid, cs, do_colsum);
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -283,38 +385,87 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {  // blocks b, b+8, ..
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-template <int AMODE, int BMODE, typename TC>
+// Persistent single-problem kernel: the grid is at most 2 workgroups per CU and every workgroup walks the tiles
+// id, id + grid, id + 2*grid, ...  The global-load pipeline (two k-tiles in flight in registers) runs ACROSS tile
+// boundaries, so the loads of the next tile's first k-tiles and the stores of the previous tile fly under the epilogue,
+// and the per-tile prologue latency is paid once per workgroup instead of once per tile.
+template <int AMODE, int BMODE, typename TC, int EPI>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bm, long ldb, TC* C, long ldc, int M, int N, int K, int tiles_n,
-            GemmEpi e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A 16 KB | B 16 KB)
+            int ntiles, GemmEpi e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A 16 KB | B 16 KB); reused as the epilogue image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int idx = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (idx / tiles_n) * BM, n0 = (idx % tiles_n) * BN;
+  const int G = gridDim.x;
+  const int first = xcd_remap(blockIdx.x, G);
+  const int T = (K + BK - 1) / BK;
+  const int T2 = (T + 1) & ~1;                    // k-steps per tile, padded to the 2-step unroll (a pad step reads zeros)
+  char* buf0 = smem;
+  char* buf1 = smem + 32768;
+  float* Cs = (float*)smem;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float cs[8];
-  gemm_mainloop<AMODE, BMODE, false>(A, lda, Bm, ldb, m0, n0, M, N, K, smem, acc, cs, false, tid, wm, wn, lane, e.dbg);
-  if ((e.dbg & 2) && acc[0][0][0] != 123.456f) return;
-  // epilogue through LDS: whole 256-B (bf16) / 512-B (fp32) row segments per 16 lanes, 16-byte accesses
-  float* Cs = (float*)smem;
-  acc_to_lds(Cs, acc, wm, wn, lane);
-  __syncthreads();
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    int row = (tid >> 4) + 16 * p, c8 = (tid & 15) * 8;
-    int m = m0 + row, n = n0 + c8;
-    if (m < M && n < N) {
-      float v[8];
-      float4 x0 = *(const float4*)(Cs + row * CS_LD + c8), x1 = *(const float4*)(Cs + row * CS_LD + c8 + 4);
-      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-      epi_store8<TC>(C, ldc, m, n, v, e, N);
+  // load side: tile `lt`, k-step `lk`
+  int lt = first, lk = 0;
+  Operand oa = make_operand<AMODE>(A, lda, (lt / tiles_n) * BM, M, K, tid);
+  Operand ob = make_operand<BMODE>(Bm, ldb, (lt % tiles_n) * BN, N, K, tid);
+  StageRegs R0, R1;
+#define ADVANCE_LOAD()                                                                    \
+  do {                                                                                    \
+    if (++lk == T2) {                                                                     \
+      lk = 0;                                                                             \
+      lt += G;                                                                            \
+      retarget_operand<AMODE>(oa, lda, (lt / tiles_n) * BM, M, tid, lt < ntiles);         \
+      retarget_operand<BMODE>(ob, ldb, (lt % tiles_n) * BN, N, tid, lt < ntiles);         \
+    }                                                                                     \
+  } while (0)
+  int nst = 0;
+#define STAMP() do { if (e.stamps && tid == 0 && nst < 32) e.stamps[(size_t)blockIdx.x * 32 + nst++] = clock64(); } while (0)
+  STAMP();
+  tile_load<AMODE, BMODE>(R0, oa, ob, lk * BK, K); ADVANCE_LOAD();
+  tile_load<AMODE, BMODE>(R1, oa, ob, lk * BK, K); ADVANCE_LOAD();
+  tile_store<AMODE, BMODE, false>(R0, buf0, tid, cs, false);
+  lds_barrier();
+  STAMP();
+  for (int ct = first; ct < ntiles; ct += G) {
+    for (int k = 0; k < T2; k += 2) {
+      STAMP();
+      tile_load<AMODE, BMODE>(R0, oa, ob, lk * BK, K); ADVANCE_LOAD();
+      tile_compute<AMODE, BMODE>(buf0, acc, wm, wn, lane);
+      tile_store<AMODE, BMODE, false>(R1, buf1, tid, cs, false);
+      lds_barrier();
+      tile_load<AMODE, BMODE>(R1, oa, ob, lk * BK, K); ADVANCE_LOAD();
+      tile_compute<AMODE, BMODE>(buf1, acc, wm, wn, lane);
+      if (k + 2 < T2) {
+        tile_store<AMODE, BMODE, false>(R0, buf0, tid, cs, false);
+        lds_barrier();
+      }
     }
+    // ---- epilogue of tile ct through LDS (whole row segments, 16-byte accesses); R0/R1 already hold the next tile's first steps
+    STAMP();
+    lds_barrier();
+    STAMP();
+    acc_to_lds(Cs, acc, wm, wn, lane);
+    lds_barrier();
+    STAMP();
+    tile_epilogue<EPI, TC>(Cs, C, ldc, (ct / tiles_n) * BM, (ct % tiles_n) * BN, M, N, e, tid);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    STAMP();
+    lds_barrier();
+    STAMP();
+    tile_store<AMODE, BMODE, false>(R0, buf0, tid, cs, false);
+    lds_barrier();
   }
+  STAMP();
+#undef STAMP
+#undef ADVANCE_LOAD
 }
 
 // ======================================================================== grouped weight-gradient GEMM
@@ -347,7 +498,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* _
     float* R = (float*)smem;  // [16 kgroups][128 cols]; the staging buffers are free after the main loop's last barrier
 #pragma unroll
     for (int i = 0; i < 8; ++i) R[(tid >> 4) * 128 + (tid & 15) * 8 + i] = cs[i];
-    __syncthreads();
+    lds_barrier();
     if (tid < 128) {
       float sum = 0.f;
 #pragma unroll
@@ -355,10 +506,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* _
       if (m0 + tid < M) P.bias_grad[m0 + tid] = sum;
     }
   }
-  __syncthreads();
+  lds_barrier();
   float* Cs = (float*)smem;
   acc_to_lds(Cs, acc, wm, wn, lane);
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     int row = (tid >> 4) + 16 * p, c8 = (tid & 15) * 8;
@@ -385,21 +536,63 @@ int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles,
   return 0;
 }
 
+static long long* g_stamps = nullptr;
+extern "C" int fc_dbg_read_stamps(long long* host, int n) {
+  if (!g_stamps) return -1;
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(host, g_stamps, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost);
+}
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-template <int AM, int BMo, typename TC>
-static int launch_gemm(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K, int tiles_n,
-                       const GemmEpi& epi, hipStream_t s) {
-  const int lds = BM * CS_LD * 4;
-  auto kfn = k_gemm_mfma<AM, BMo, TC>;
+template <int AM, int BMo, typename TC, int EPI>
+static int launch_gemm_epi(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K, int tiles_n,
+                           const GemmEpi& epi, hipStream_t s) {
+  const int lds = BM * CS_LD * 4;  // 67,584 B (> the 65,536 B staging image)
+  auto kfn = k_gemm_mfma<AM, BMo, TC, EPI>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kfn, dim3(tiles), dim3(256), lds, s, A, lda, Bm, ldb, (TC*)C, ldc, M, N, K, tiles_n, epi);
+  static int max_wg = 0;
+  if (!max_wg) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    max_wg = 2 * cus;   // 67.5 KB of LDS per workgroup: two are resident per CU
+  }
+  int grid = tiles < max_wg ? tiles : max_wg;
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, A, lda, Bm, ldb, (TC*)C, ldc, M, N, K, tiles_n, tiles, epi);
   FC_LAUNCH_CHECK();
   return 0;
+}
+static int epi_kind(const GemmEpi& e) {
+  if (e.accumulate || e.dbg) return EPI_GENERIC;
+  int extras = (e.res != nullptr) + (e.preact != nullptr) + (e.gelu_in != nullptr) + (e.patch_rows > 0);
+  if (extras > 1) return EPI_GENERIC;
+  if (e.patch_rows > 0) return e.bias ? EPI_PATCH : EPI_GENERIC;
+  if (e.preact) return (e.bias && !e.rowscale) ? EPI_GELU : EPI_GENERIC;
+  if (e.gelu_in) return (!e.bias && !e.rowscale) ? EPI_GELU_GRAD : EPI_GENERIC;
+  if (e.res) return !e.bias ? EPI_GENERIC : (e.rowscale ? EPI_RES_SCALE : EPI_RES);
+  if (e.rowscale) return EPI_GENERIC;
+  return e.bias ? EPI_BIAS : EPI_PLAIN;
+}
+// the epilogue kinds each GEMM form is instantiated for (anything else takes the run-time-flag EPI_GENERIC body)
+template <int AM, int BMo, typename TC>
+static int launch_gemm(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K, int tiles_n,
+                       const GemmEpi& epi, hipStream_t s) {
+#define GO(E) return launch_gemm_epi<AM, BMo, TC, E>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s)
+  const int k = epi_kind(epi);
+  if (AM == KC && BMo == KC && sizeof(TC) == 2) {   // forward linears
+    switch (k) { case EPI_BIAS: GO(EPI_BIAS); case EPI_RES: GO(EPI_RES); case EPI_RES_SCALE: GO(EPI_RES_SCALE); case EPI_GELU: GO(EPI_GELU);
+                 case EPI_PATCH: GO(EPI_PATCH); case EPI_PLAIN: GO(EPI_PLAIN); }
+  } else if (AM == KC && BMo == KR && sizeof(TC) == 2) {   // dX
+    switch (k) { case EPI_PLAIN: GO(EPI_PLAIN); case EPI_GELU_GRAD: GO(EPI_GELU_GRAD); case EPI_BIAS: GO(EPI_BIAS); }
+  } else {
+    switch (k) { case EPI_PLAIN: GO(EPI_PLAIN); case EPI_BIAS: GO(EPI_BIAS); }
+  }
+  GO(EPI_GENERIC);
+#undef GO
 }
 
 int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K,
@@ -420,6 +613,12 @@ int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm,
   static int dbg = getenv("FC_GEMM_DBG") ? atoi(getenv("FC_GEMM_DBG")) : 0;
   GemmEpi epi = epi_in;
   epi.dbg = dbg;
+  long long*& stamps = g_stamps;
+  if (getenv("FC_GEMM_STAMPS")) {
+    if (!stamps) { (void)hipMalloc(&stamps, 4096 * 32 * sizeof(long long)); }
+    (void)hipMemsetAsync(stamps, 0, 4096 * 32 * sizeof(long long), s);
+    epi.stamps = stamps;
+  }
   if (kind == FC_GEMM_NT) {
     if (dtC == FC_BF16) return launch_gemm<KC, KC, bf16_t>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
     return launch_gemm<KC, KC, float>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
@@ -432,3 +631,4 @@ int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm,
   if (dtC != FC_F32) return 1;
   return launch_gemm<KR, KR, float>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
 }
+
