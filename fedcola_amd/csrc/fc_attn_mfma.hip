@@ -128,43 +128,63 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(const bf16_t* __restrict_
 }
 
 // ======================================================================== backward
+// Two kernels, each with two tiles (56 KB for N = 197) in LDS so that two workgroups share a CU, each (batch, head) split
+// over two workgroups, inner loops fully unrolled so that independent MFMA chains overlap:
+//   k_attn_bwd_dq : K, V tiles in LDS; Q / dO / O fragments straight from global; waves split the query blocks
+//   k_attn_bwd_dkv: Q, dO tiles in LDS; K / V fragments straight from global; waves split the key blocks (no atomics)
+// delta = rowsum(dO * O) is recomputed inside both kernels (no separate pass, no delta round trip through HBM).
+__device__ __forceinline__ bf16x8 gfrag(const bf16_t* __restrict__ base, long ld, int row, int N, int ks, int g) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (row < N) v = *(const uint4*)(base + (size_t)row * ld + ks * 32 + g * 8);
+  return *(bf16x8*)&v;
+}
+__device__ __forceinline__ float dot8(const bf16x8& a, const bf16x8& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += bf2f((bf16_t)a[i]) * bf2f((bf16_t)b[i]);
+  return s;
+}
+
 template <int NF>
-__global__ void __launch_bounds__(256, 1) k_attn_bwd_mfma(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
+__global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = 16 * NF;
-  char* Qs = smem;
-  char* Ks = Qs + NP * 128;
-  char* Vs = Ks + NP * 128;
-  char* Ds = Vs + NP * 128;
-  float* lse_s = (float*)(Ds + NP * 128);
-  float* del_s = lse_s + NP;
+  char* Ks = smem;
+  char* Vs = smem + NP * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bh = blockIdx.x >> 1, part = blockIdx.x & 1;
+  const int b = bh / H, h = bh % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
-  stage_tile(Qs, base, D3, N, NP, tid);
+  const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
+  const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
   stage_tile(Ks, base + Dm, D3, N, NP, tid);
   stage_tile(Vs, base + 2 * Dm, D3, N, NP, tid);
-  stage_tile(Ds, dout + (size_t)b * N * Dm + h * 64, Dm, N, NP, tid);
-  for (int i = tid; i < NP; i += 256) {
-    lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] : 1e30f;     // padded queries: P = exp(. - 1e30) = 0
-    del_s[i] = i < N ? delta[((size_t)b * H + h) * N + i] : 0.f;
-  }
   __syncthreads();
   bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
   const int nqb = (N + 15) >> 4;
-  // ---------------- phase 1: dQ.  tiles S^T / dP^T (rows = keys, cols = queries)
-  for (int qb = wave; qb < nqb; qb += 4) {
+  for (int qb = part + 2 * wave; qb < nqb; qb += 8) {
+    const int qrow = qb * 16 + cl;
     bf16x8 qf[2], dof[2];
+    float dl = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { qf[ks] = row_frag(Qs, qb * 16, ks, lane); dof[ks] = row_frag(Ds, qb * 16, ks, lane); }
-    const float lq = lse_s[qb * 16 + cl], dq_ = del_s[qb * 16 + cl];
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = gfrag(base, D3, qrow, N, ks, g);
+      dof[ks] = gfrag(dobase, Dm, qrow, N, ks, g);
+      dl += dot8(dof[ks], gfrag(obase, Dm, qrow, N, ks, g));
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);                                      // delta[q = cl]
+    const float lq = qrow < N ? lse[((size_t)b * H + h) * N + qrow] : 1e30f;
     f32x4 dq[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int ss = 0; ss < NF / 2; ++ss) {
+    for (int sp = 0; sp < (NF / 2 + 1) / 2; ++sp)
+#pragma unroll
+    for (int ss = 2 * sp; ss < 2 * sp + 2; ++ss) {
+      if (ss >= NF / 2) break;
       f32x4 ds[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -173,12 +193,12 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_mfma(const bf16_t* __restri
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           st = MFMA(row_frag(Ks, f * 16, ks, lane), qf[ks], st);        // S^T[key][q]
-          dpt = MFMA(row_frag(Vs, f * 16, ks, lane), dof[ks], dpt);     // dP^T[key][q] = sum_d V[key][d] dO[q][d]
+          dpt = MFMA(row_frag(Vs, f * 16, ks, lane), dof[ks], dpt);     // dP^T[key][q]
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x) ds[hh][x] = __expf(st[x] * scale - lq) * (dpt[x] - dq_);
+        for (int x = 0; x < 4; ++x) ds[hh][x] = __expf(st[x] * scale - lq) * (dpt[x] - dl);
       }
-      bf16x8 af = pack8(ds[0], ds[1]);                                  // A[row = q][k = key(8g+j)]
+      bf16x8 af = pack8(ds[0], ds[1]);
 #pragma unroll
       for (int db = 0; db < 4; ++db) dq[db] = MFMA(af, tr_frag(Ks, 32 * ss, db * 16, lane), dq[db]);   // dQ[q = 4g+x][d = 16db+cl]
     }
@@ -192,17 +212,59 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_mfma(const bf16_t* __restri
       }
     }
   }
-  // ---------------- phase 2: dK, dV.  tiles S / dP (rows = queries, cols = keys)
-  for (int f = wave; f < NF; f += 4) {
+}
+
+template <int NF>
+__global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = 16 * NF;
+  char* Qs = smem;
+  char* Ds = smem + NP * 128;
+  float* lse_s = (float*)(Ds + NP * 128);
+  float* del_s = lse_s + NP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
+  const int bh = blockIdx.x >> 1, part = blockIdx.x & 1;
+  const int b = bh / H, h = bh % H;
+  const long D3 = 3L * H * 64, Dm = (long)H * 64;
+  const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
+  const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
+  const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
+  stage_tile(Qs, base, D3, N, NP, tid);
+  // stage dO and form delta = rowsum(dO * O): a row's 8 chunks sit in 8 consecutive lanes
+  for (int idx = tid; idx < NP * 8; idx += 256) {
+    int row = idx >> 3, c = idx & 7;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u), ov = make_uint4(0u, 0u, 0u, 0u);
+    if (row < N) {
+      v = *(const uint4*)(dobase + (size_t)row * Dm + c * 8);
+      ov = *(const uint4*)(obase + (size_t)row * Dm + c * 8);
+    }
+    *(uint4*)(Ds + at_off(row, c)) = v;
+    float d = dot8(*(bf16x8*)&v, *(bf16x8*)&ov);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if (c == 0) {
+      del_s[row] = d;
+      lse_s[row] = row < N ? lse[((size_t)b * H + h) * N + row] : 1e30f;   // padded queries: P = exp(. - 1e30) = 0
+    }
+  }
+  __syncthreads();
+  bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
+  for (int f = part + 2 * wave; f < NF; f += 8) {
     if (f * 16 >= N) break;
+    const int krow = f * 16 + cl;
     bf16x8 kfb[2], vfb[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { kfb[ks] = row_frag(Ks, f * 16, ks, lane); vfb[ks] = row_frag(Vs, f * 16, ks, lane); }
+    for (int ks = 0; ks < 2; ++ks) { kfb[ks] = gfrag(base + Dm, D3, krow, N, ks, g); vfb[ks] = gfrag(base + 2 * Dm, D3, krow, N, ks, g); }
     f32x4 dv[4], dk[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dv[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
-    for (int qp = 0; qp < NF / 2; ++qp) {
+    for (int qq = 0; qq < (NF / 2 + 1) / 2; ++qq)
+#pragma unroll
+    for (int qp = 2 * qq; qp < 2 * qq + 2; ++qp) {
+      if (qp >= NF / 2) break;
       f32x4 P[2], dS[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -211,7 +273,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_mfma(const bf16_t* __restri
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           sa = MFMA(row_frag(Qs, qb * 16, ks, lane), kfb[ks], sa);      // S[q = 4g+x][key = cl]
-          dpa = MFMA(row_frag(Ds, qb * 16, ks, lane), vfb[ks], dpa);    // dP[q][key] = sum_d dO[q][d] V[key][d]
+          dpa = MFMA(row_frag(Ds, qb * 16, ks, lane), vfb[ks], dpa);    // dP[q][key]
         }
         const float4 l4 = *(const float4*)(lse_s + qb * 16 + 4 * g), d4 = *(const float4*)(del_s + qb * 16 + 4 * g);
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -256,13 +318,19 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, in
   return 0;
 }
 template <int NF>
-static int launch_bwd(const bf16_t* qkv, const bf16_t* dout, const float* lse, const float* delta, bf16_t* dqkv, int B, int N, int H, float scale,
+static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, bf16_t* dqkv, int B, int N, int H, float scale,
                       hipStream_t s) {
-  const int lds = 4 * 16 * NF * 128 + 2 * 16 * NF * 4;
-  auto k = k_attn_bwd_mfma<NF>;
+  const int lds_q = 2 * 16 * NF * 128, lds_kv = 2 * 16 * NF * 128 + 2 * 16 * NF * 4;
+  auto kq = k_attn_bwd_dq<NF>;
+  auto kkv = k_attn_bwd_dkv<NF>;
   static bool done = false;
-  if (!done) { FC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); done = true; }
-  hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, s, qkv, dout, lse, delta, dqkv, B, N, H, scale);
+  if (!done) {
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q));
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
+    done = true;
+  }
+  hipLaunchKernelGGL(kq, dim3(B * H * 2), dim3(256), lds_q, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  hipLaunchKernelGGL(kkv, dim3(B * H * 2), dim3(256), lds_kv, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
   FC_LAUNCH_CHECK();
   return 0;
 }
@@ -278,30 +346,15 @@ int fc_attn_fwd_mfma(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int
   return 1;
 }
 
-// delta[b,h,q] = sum_d dO[q,d] O[q,d]  (one wave per row; 64 lanes = 64 head dims)
-__global__ void __launch_bounds__(256) k_attn_delta64(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta, int B, int N,
-                                                      int H) {
-  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  int lane = threadIdx.x & 63;
-  if (row >= (long)B * H * N) return;
-  int i = (int)(row % N), h = (int)((row / N) % H), b = (int)(row / ((long)N * H));
-  size_t off = ((size_t)b * N + i) * (H * 64) + h * 64 + lane;
-  float s = wave_sum(bf2f(o[off]) * bf2f(dout[off]));
-  if (lane == 0) delta[row] = s;
-}
-
 int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv, int B, int N, int H,
                      int d, float scale, hipStream_t s) {
-  if (d != 64 || ((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15)) return 1;
-  int nf = pick_nf(N);
-  if (!nf) return 1;
-  hipLaunchKernelGGL(k_attn_delta64, dim3(fc_cdiv((long)B * H * N, 4)), dim3(256), 0, s, o, dout, delta, B, N, H);
-  FC_LAUNCH_CHECK();
-  switch (nf) {
-    case 2: return launch_bwd<2>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
-    case 4: return launch_bwd<4>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
-    case 14: return launch_bwd<14>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
-    case 16: return launch_bwd<16>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
+  (void)delta;   // recomputed in-kernel
+  if (d != 64 || ((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)o & 15)) return 1;
+  switch (pick_nf(N)) {
+    case 2: return launch_bwd<2>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+    case 4: return launch_bwd<4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+    case 14: return launch_bwd<14>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+    case 16: return launch_bwd<16>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
   }
   return 1;
 }
