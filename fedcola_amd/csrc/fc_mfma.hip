@@ -310,6 +310,173 @@ __device__ __forceinline__ void tile_epilogue(const float* Cs, TC* C, long ldc, 
   }
 }
 
+// ---- direct-to-LDS staging (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write.  One wave-instruction fills 1 KB
+// of LDS linearly (lane L -> base + 16 L), so the swizzle is applied to the per-lane SOURCE address instead: wave w owns
+// the 1-KB pieces 4w .. 4w+3 of each 16-KB operand tile.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int MODE>
+__device__ __forceinline__ Operand make_operand_glds(const bf16_t* P, long ld, int row0, int nrows, int K, int wave, int lane) {
+  Operand o;
+  unsigned long long base = (unsigned long long)P;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+  const void* up = (const void*)(((unsigned long long)hi << 32) | lo);
+  long rows = (MODE == KC) ? nrows : K;
+  unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(((rows - 1) * ld + ((MODE == KC) ? K : nrows)) * 2));
+  o.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)up, 0, (int)bytes, 0x00020000);
+  o.kstride = (MODE == KC) ? 2u : (unsigned)(ld * 2);
+  o.c8 = 0;
+  return o;
+}
+template <int MODE>
+__device__ __forceinline__ void retarget_glds(Operand& o, long ld, int row0, int nrows, int wave, int lane, bool valid) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int piece = wave * 4 + p;
+    if (MODE == KC) {   // piece = 8 rows x 128 B; lane -> (row, physical chunk)
+      int row = piece * 8 + (lane >> 3), pc = lane & 7;
+      int c = pc ^ ((row >> 1) & 7);
+      int r = row0 + row;
+      if (p == 0) o.c8 = c * 8;                           // (c differs per piece only through the row swizzle; see stage_glds)
+      o.voff[p] = (valid && r < nrows) ? (unsigned)((r * ld + c * 8) * 2) : FC_OOB;
+    } else {            // piece = 4 k-rows x 256 B; lane -> (k row, physical 16-B chunk)
+      int k = piece * 4 + (lane >> 4), pc = lane & 15;
+      int sw = (((k >> 3) & 1) << 2) | (k & 3);
+      int c = (((pc >> 1) ^ sw) << 1) | (pc & 1);
+      int col = row0 + c * 8;
+      o.voff[p] = (valid && col < nrows) ? (unsigned)((k * ld + col) * 2) : FC_OOB;
+    }
+  }
+}
+// issue the 4 pieces of one operand tile for k-tile k0 into `buf` (16 KB)
+template <int MODE>
+__device__ __forceinline__ void stage_glds(const Operand& o, char* buf, int k0, int K, int wave, int lane) {
+  const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)k0 * o.kstride));
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned vo = o.voff[p];
+    if (MODE == KC) {  // k tail (K % 64 != 0): this lane's logical chunk within the tile
+      int row = (wave * 4 + p) * 8 + (lane >> 3);
+      int c = (lane & 7) ^ ((row >> 1) & 7);
+      vo = (k0 + c * 8 < K) ? vo : FC_OOB;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rsrc, (lds_ptr_t)(buf + (wave * 4 + p) * 1024), 16, vo, soff, 0, 0);
+  }
+}
+
+// 64-row epilogue image in ONE 32-KB staging buffer: rows of 128 floats, float4 slot s of row r stored at slot s ^ (r & 7)
+// (conflict-free for the accumulator writes -- 8 lanes, 8 rows, one column slot -- and for the row reads).
+__device__ __forceinline__ int cs_slot(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 2); }
+// half hp of the tile = rows {64 wm + 32 hp + r, r < 32}: image row = 32 wm + r, every wave contributes two row-fragments
+template <int HP>
+__device__ __forceinline__ void acc_to_lds_half(float* Cs, const f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+  const int g = lane >> 4, cl = lane & 15;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *(float4*)(Cs + cs_slot(wm * 32 + ii * 16 + cl, wn * 16 + j * 4 + g)) =
+          make_float4(acc[2 * HP + ii][j][0], acc[2 * HP + ii][j][1], acc[2 * HP + ii][j][2], acc[2 * HP + ii][j][3]);
+}
+// buffer descriptor for the epilogue stores: lanes outside the matrix use an out-of-range offset, so every thread issues the
+// SAME number of store instructions per tile and the main loop can use a counted s_waitcnt that skips them
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_store_rsrc(void* p, long bytes) {
+  unsigned long long base = (unsigned long long)p;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+  void* up = (void*)(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(up, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+template <typename TC>
+__device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, size_t elem_off, bool ok, const float (&v)[8]) {
+  if (sizeof(TC) == 2) {
+    uint4 u = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+    __builtin_amdgcn_raw_buffer_store_b128(*(v4u*)&u, r, ok ? (unsigned)(elem_off * 2) : FC_OOB, 0, 0);
+  } else {
+    float4 a = make_float4(v[0], v[1], v[2], v[3]), b = make_float4(v[4], v[5], v[6], v[7]);
+    __builtin_amdgcn_raw_buffer_store_b128(*(v4u*)&a, r, ok ? (unsigned)(elem_off * 4) : FC_OOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(*(v4u*)&b, r, ok ? (unsigned)(elem_off * 4 + 16) : FC_OOB, 0, 0);
+  }
+}
+// store instructions one thread issues per output tile with the compile-time epilogues (0: unknown -> full drain)
+template <int EPI, typename TC> struct EpiStores { static constexpr int n = EPI == EPI_GENERIC ? 0 : (EPI == EPI_GELU ? 16 : 8) * (sizeof(TC) == 2 ? 1 : 2); };
+// one half (64 rows starting at tile row `rbase`) of the fused epilogue; thread owns columns 8*(tid&15).. and rows (tid>>4) + 16q
+template <int EPI, typename TC>
+__device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid, int hp,
+                                              __amdgpu_buffer_rsrc_t crs, __amdgpu_buffer_rsrc_t prs) {
+  const int c8 = (tid & 15) * 8, n = n0 + c8, r0 = tid >> 4;
+#define TILE_ROW(row) ((((row) >> 5) << 6) + hp * 32 + ((row) & 31))   /* image row -> row inside the 128-row tile */
+  if (EPI == EPI_GENERIC) {
+    if (n >= N) return;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      int row = r0 + 16 * q, m = m0 + TILE_ROW(row);
+      if (m < M) {
+        float v[8];
+        float4 x0 = *(const float4*)(Cs + cs_slot(row, (tid & 15) * 2)), x1 = *(const float4*)(Cs + cs_slot(row, (tid & 15) * 2 + 1));
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        epi_store8<TC>(C, ldc, m, n, v, e, N);
+      }
+    }
+    return;
+  }
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_PATCH;
+  constexpr bool HAS_RES = EPI == EPI_RES || EPI == EPI_RES_SCALE;
+  const int nc = n < N ? n : N - 8;
+  float bias[8];
+  if (HAS_BIAS) Vec8<float>::ld(e.bias + nc, bias);
+  float rin[4][8], rpos[4][8], sc[4];
+  size_t off[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + TILE_ROW(r0 + 16 * q);
+    const int mc = m < M ? m : M - 1;
+    long orow = mc;
+    if (EPI == EPI_PATCH) orow = (long)mc + mc / e.patch_rows + 1;
+    off[q] = (size_t)orow * ldc + nc;
+    if (HAS_RES) Vec8<TC>::ld((const TC*)e.res + off[q], rin[q]);
+    if (EPI == EPI_GELU_GRAD) Vec8<TC>::ld((const TC*)e.gelu_in + off[q], rin[q]);
+    if (EPI == EPI_PATCH) Vec8<float>::ld(e.pos + (size_t)(1 + mc % e.patch_rows) * N + nc, rpos[q]);
+    if (EPI == EPI_RES_SCALE) sc[q] = e.rowscale[mc / e.rows_per_sample];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = r0 + 16 * q;
+    const int trow = TILE_ROW(row);
+    float v[8];
+    float4 x0 = *(const float4*)(Cs + cs_slot(row, (tid & 15) * 2)), x1 = *(const float4*)(Cs + cs_slot(row, (tid & 15) * 2 + 1));
+    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+    if (HAS_BIAS) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += bias[i];
+    }
+    if (EPI == EPI_PATCH) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += rpos[q][i];
+    }
+    const bool ok = (m0 + trow < M) && (n < N);
+    if (EPI == EPI_GELU) {
+      buf_store8<TC>(prs, off[q], ok, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = gelu_fast(v[i]);
+    }
+    if (EPI == EPI_GELU_GRAD) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= gelu_fast_grad(rin[q][i]);
+    }
+    if (EPI == EPI_RES_SCALE) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= sc[q];
+    }
+    if (HAS_RES) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += rin[q][i];
+    }
+    buf_store8<TC>(crs, off[q], ok, v);
+  }
+#undef TILE_ROW
+}
+
 // ---- main loop shared by the single-problem and the grouped kernels.
 // Operands are swapped in the MFMA (D' = B.A^T) so that acc[i][j][x] = C[m = 16i + lane&15][n = 16j + 4(lane>>4) + x]:
 // a lane then owns 4 consecutive output columns and the epilogue needs no LDS round trip.
@@ -386,86 +553,81 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {  // blocks b, b+8, ..
 }
 
 // Persistent single-problem kernel: the grid is at most 2 workgroups per CU and every workgroup walks the tiles
-// id, id + grid, id + 2*grid, ...  The global-load pipeline (two k-tiles in flight in registers) runs ACROSS tile
-// boundaries, so the loads of the next tile's first k-tiles and the stores of the previous tile fly under the epilogue,
-// and the per-tile prologue latency is paid once per workgroup instead of once per tile.
+// id, id + grid, id + 2*grid, ...  Operand tiles stream global -> LDS directly (LDS-DMA), double-buffered: the loads of
+// k-tile t+1 (or of the NEXT output tile's first k-tile) are in flight while k-tile t feeds the MFMAs and while the
+// epilogue runs.  One barrier per k-tile: wait for own DMA (vmcnt) -> barrier -> issue next DMA -> compute.
 template <int AMODE, int BMODE, typename TC, int EPI>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bm, long ldb, TC* C, long ldc, int M, int N, int K, int tiles_n,
             int ntiles, GemmEpi e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A 16 KB | B 16 KB); reused as the epilogue image
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A 16 KB | B 16 KB) + a separate epilogue image
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int G = gridDim.x;
   const int first = xcd_remap(blockIdx.x, G);
   const int T = (K + BK - 1) / BK;
-  const int T2 = (T + 1) & ~1;                    // k-steps per tile, padded to the 2-step unroll (a pad step reads zeros)
-  char* buf0 = smem;
-  char* buf1 = smem + 32768;
-  float* Cs = (float*)smem;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float cs[8];
-  // load side: tile `lt`, k-step `lk`
-  int lt = first, lk = 0;
-  Operand oa = make_operand<AMODE>(A, lda, (lt / tiles_n) * BM, M, K, tid);
-  Operand ob = make_operand<BMODE>(Bm, ldb, (lt % tiles_n) * BN, N, K, tid);
-  StageRegs R0, R1;
-#define ADVANCE_LOAD()                                                                    \
-  do {                                                                                    \
-    if (++lk == T2) {                                                                     \
-      lk = 0;                                                                             \
-      lt += G;                                                                            \
-      retarget_operand<AMODE>(oa, lda, (lt / tiles_n) * BM, M, tid, lt < ntiles);         \
-      retarget_operand<BMODE>(ob, ldb, (lt % tiles_n) * BN, N, tid, lt < ntiles);         \
-    }                                                                                     \
+  // load side: tile `lt`, k-tile `lk`, destination buffer parity `lb`
+  int lt = first, lk = 0, lb = 0;
+  Operand oa = make_operand_glds<AMODE>(A, lda, 0, M, K, wave, lane);
+  Operand ob = make_operand_glds<BMODE>(Bm, ldb, 0, N, K, wave, lane);
+  retarget_glds<AMODE>(oa, lda, (lt / tiles_n) * BM, M, wave, lane, lt < ntiles);
+  retarget_glds<BMODE>(ob, ldb, (lt % tiles_n) * BN, N, wave, lane, lt < ntiles);
+#define ISSUE_NEXT()                                                                   \
+  do {                                                                                 \
+    char* dst = smem + lb * 32768;                                                     \
+    stage_glds<AMODE>(oa, dst, lk * BK, K, wave, lane);                                \
+    stage_glds<BMODE>(ob, dst + 16384, lk * BK, K, wave, lane);                        \
+    lb ^= 1;                                                                           \
+    if (++lk == T) {                                                                   \
+      lk = 0;                                                                          \
+      lt += G;                                                                         \
+      retarget_glds<AMODE>(oa, lda, (lt / tiles_n) * BM, M, wave, lane, lt < ntiles);  \
+      retarget_glds<BMODE>(ob, ldb, (lt % tiles_n) * BN, N, wave, lane, lt < ntiles);  \
+    }                                                                                  \
   } while (0)
-  int nst = 0;
-#define STAMP() do { if (e.stamps && tid == 0 && nst < 32) e.stamps[(size_t)blockIdx.x * 32 + nst++] = clock64(); } while (0)
-  STAMP();
-  tile_load<AMODE, BMODE>(R0, oa, ob, lk * BK, K); ADVANCE_LOAD();
-  tile_load<AMODE, BMODE>(R1, oa, ob, lk * BK, K); ADVANCE_LOAD();
-  tile_store<AMODE, BMODE, false>(R0, buf0, tid, cs, false);
-  lds_barrier();
-  STAMP();
+  ISSUE_NEXT();                      // k-tile 0 of the first tile -> buffer 0
+  int cb = 0;                        // buffer holding the k-tile to compute next
+  const long crows = (long)M + (e.patch_rows > 0 ? M / e.patch_rows + 2 : 0);
+  const __amdgpu_buffer_rsrc_t crs = make_store_rsrc((void*)C, crows * ldc * (long)sizeof(TC));
+  const __amdgpu_buffer_rsrc_t prs = make_store_rsrc(e.preact ? e.preact : (void*)C, crows * ldc * (long)sizeof(TC));
+  constexpr int NST = EpiStores<EPI, TC>::n;
   for (int ct = first; ct < ntiles; ct += G) {
-    for (int k = 0; k < T2; k += 2) {
-      STAMP();
-      tile_load<AMODE, BMODE>(R0, oa, ob, lk * BK, K); ADVANCE_LOAD();
-      tile_compute<AMODE, BMODE>(buf0, acc, wm, wn, lane);
-      tile_store<AMODE, BMODE, false>(R1, buf1, tid, cs, false);
-      lds_barrier();
-      tile_load<AMODE, BMODE>(R1, oa, ob, lk * BK, K); ADVANCE_LOAD();
-      tile_compute<AMODE, BMODE>(buf1, acc, wm, wn, lane);
-      if (k + 2 < T2) {
-        tile_store<AMODE, BMODE, false>(R0, buf0, tid, cs, false);
-        lds_barrier();
-      }
+    for (int k = 0; k < T; ++k) {
+      // this wave's pieces of the current k-tile have landed.  Right after an epilogue the youngest NST operations are that
+      // epilogue's stores (a fixed count per thread): skip them instead of draining the HBM write latency.
+      if (NST > 0 && k == 0 && ct != first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // ... everyone's have, and the other buffer is no longer being read
+      asm volatile("" ::: "memory");
+      ISSUE_NEXT();                                        // next k-tile (possibly of the next output tile) -> other buffer
+      tile_compute<AMODE, BMODE>(smem + cb * 32768, acc, wm, wn, lane);
+      cb ^= 1;
     }
-    // ---- epilogue of tile ct through LDS (whole row segments, 16-byte accesses); R0/R1 already hold the next tile's first steps
-    STAMP();
+    // ---- epilogue, two 64-row halves through the staging buffer that was computed last (the other one is receiving the
+    // next tile's first k-tile by DMA meanwhile)
+    float* Cs = (float*)(smem + (cb ^ 1) * 32768);
+    const int m0 = (ct / tiles_n) * BM, n0 = (ct % tiles_n) * BN;
+    lds_barrier();                                         // last MFMA fragment reads of this buffer are done
+    acc_to_lds_half<0>(Cs, acc, wm, wn, lane);
     lds_barrier();
-    STAMP();
-    acc_to_lds(Cs, acc, wm, wn, lane);
+    half_epilogue<EPI, TC>(Cs, C, ldc, m0, n0, M, N, e, tid, 0, crs, prs);
     lds_barrier();
-    STAMP();
-    tile_epilogue<EPI, TC>(Cs, C, ldc, (ct / tiles_n) * BM, (ct % tiles_n) * BN, M, N, e, tid);
+    acc_to_lds_half<1>(Cs, acc, wm, wn, lane);
+    lds_barrier();
+    half_epilogue<EPI, TC>(Cs, C, ldc, m0, n0, M, N, e, tid, 1, crs, prs);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    STAMP();
-    lds_barrier();
-    STAMP();
-    tile_store<AMODE, BMODE, false>(R0, buf0, tid, cs, false);
-    lds_barrier();
+    lds_barrier();                                         // image reads done before the next DMA may target this buffer
   }
-  STAMP();
-#undef STAMP
-#undef ADVANCE_LOAD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef ISSUE_NEXT
 }
 
 // ======================================================================== grouped weight-gradient GEMM
@@ -547,7 +709,7 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 template <int AM, int BMo, typename TC, int EPI>
 static int launch_gemm_epi(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K, int tiles_n,
                            const GemmEpi& epi, hipStream_t s) {
-  const int lds = BM * CS_LD * 4;  // 67,584 B (> the 65,536 B staging image)
+  const int lds = 65536;  // two 32-KB staging buffers; the epilogue image aliases the idle one
   auto kfn = k_gemm_mfma<AM, BMo, TC, EPI>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
@@ -559,7 +721,7 @@ static int launch_gemm_epi(int tiles, const bf16_t* A, long lda, const bf16_t* B
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    max_wg = 2 * cus;   // 67.5 KB of LDS per workgroup: two are resident per CU
+    max_wg = 2 * cus;   // 64 KB of LDS per workgroup: two per CU
   }
   int grid = tiles < max_wg ? tiles : max_wg;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, A, lda, Bm, ldb, (TC*)C, ldc, M, N, K, tiles_n, tiles, epi);
