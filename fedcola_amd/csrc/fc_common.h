@@ -111,6 +111,7 @@ struct GemmEpi {
   int rows_per_sample = 1;          // rowscale index = m / rows_per_sample
   void* preact = nullptr;           // if set: store (acc+bias) here (output type) and write gelu(acc+bias) to C
   const void* gelu_in = nullptr;    // if set: C = acc * gelu'(gelu_in[m,n])   (output type)
+  int gelu_saved_grad = 0;          // preact receives gelu'(acc+bias) instead of (acc+bias); gelu_in then already holds gelu'
   int accumulate = 0;               // C += result (fp32 C only)
   int out_zeroed = 0;               // caller guarantees C is zero-filled (split-K kernels skip their own memset)
   float alpha = 1.0f;               // result = alpha*acc (+bias...)

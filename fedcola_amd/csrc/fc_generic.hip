@@ -19,10 +19,13 @@ __device__ inline void epi_store(TC* C, long ldc, int m, int n, float acc, const
   }
   size_t oidx = (size_t)orow * ldc + n;
   if (e.preact) {
-    Io<TC>::st((TC*)e.preact, oidx, v);
+    Io<TC>::st((TC*)e.preact, oidx, e.gelu_saved_grad ? gelu_erf_grad(v) : v);
     v = gelu_erf(v);
   }
-  if (e.gelu_in) v *= gelu_erf_grad(Io<TC>::ld((const TC*)e.gelu_in, oidx));
+  if (e.gelu_in) {
+    float u = Io<TC>::ld((const TC*)e.gelu_in, oidx);
+    v *= e.gelu_saved_grad ? u : gelu_erf_grad(u);
+  }
   if (e.rowscale) v *= e.rowscale[m / e.rows_per_sample];
   if (e.res) v += Io<TC>::ld((const TC*)e.res, oidx);
   if (e.accumulate) v += Io<TC>::ld(C, oidx);

@@ -185,7 +185,14 @@ __device__ __forceinline__ void epi_store8(TC* C, long ldc, int m, int n, float 
   }
   size_t o = (size_t)orow * ldc + n;
   if (e.preact) {
-    Vec8<TC>::st((TC*)e.preact + o, v);
+    if (e.gelu_saved_grad) {
+      float gp[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gp[i] = gelu_erf_grad(v[i]);
+      Vec8<TC>::st((TC*)e.preact + o, gp);
+    } else {
+      Vec8<TC>::st((TC*)e.preact + o, v);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
   }
@@ -193,7 +200,7 @@ __device__ __forceinline__ void epi_store8(TC* C, long ldc, int m, int n, float 
     float u[8];
     Vec8<TC>::ld((const TC*)e.gelu_in + o, u);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] *= gelu_erf_grad(u[i]);
+    for (int i = 0; i < 8; ++i) v[i] *= e.gelu_saved_grad ? u[i] : gelu_erf_grad(u[i]);
   }
   if (e.rowscale) {
     float s = e.rowscale[m / e.rows_per_sample];
@@ -231,7 +238,7 @@ __device__ __forceinline__ void acc_to_lds(float* Cs, const f32x4 (&acc)[4][4], 
 // unconditional (rows past M are clamped for the loads and masked for the stores), so hipcc can issue the whole batch and
 // use counted waits.  (With run-time option flags each optional load sat in its own basic block behind an
 // s_waitcnt vmcnt(0), which also drained the register prefetch pipeline: 17k cycles per tile instead of ~2k.)
-enum { EPI_PLAIN = 0, EPI_BIAS, EPI_RES, EPI_RES_SCALE, EPI_GELU, EPI_GELU_GRAD, EPI_PATCH, EPI_GENERIC };
+enum { EPI_PLAIN = 0, EPI_BIAS, EPI_RES, EPI_RES_SCALE, EPI_GELU, EPI_GELU_GRAD, EPI_PATCH, EPI_GENERIC, EPI_GELU_SG, EPI_MUL };
 
 template <int EPI, typename TC>
 __device__ __forceinline__ void tile_epilogue(const float* Cs, TC* C, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid) {
@@ -250,7 +257,7 @@ __device__ __forceinline__ void tile_epilogue(const float* Cs, TC* C, long ldc, 
     }
     return;
   }
-  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_PATCH;
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_GELU_SG || EPI == EPI_PATCH;
   constexpr bool HAS_RES = EPI == EPI_RES || EPI == EPI_RES_SCALE;
   const int nc = n < N ? n : N - 8;                     // clamped column for the loads
   float bias[8];
@@ -267,7 +274,7 @@ __device__ __forceinline__ void tile_epilogue(const float* Cs, TC* C, long ldc, 
       if (EPI == EPI_PATCH) orow = (long)mc + mc / e.patch_rows + 1;
       off[q] = (size_t)orow * ldc + nc;
       if (HAS_RES) Vec8<TC>::ld((const TC*)e.res + off[q], rin[q]);
-      if (EPI == EPI_GELU_GRAD) Vec8<TC>::ld((const TC*)e.gelu_in + off[q], rin[q]);
+      if (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) Vec8<TC>::ld((const TC*)e.gelu_in + off[q], rin[q]);
       if (EPI == EPI_PATCH) Vec8<float>::ld(e.pos + (size_t)(1 + mc % e.patch_rows) * N + nc, rpos[q]);
       if (EPI == EPI_RES_SCALE) sc[q] = e.rowscale[mc / e.rows_per_sample];
     }
@@ -397,7 +404,7 @@ __device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, size_t elem
   }
 }
 // store instructions one thread issues per output tile with the compile-time epilogues (0: unknown -> full drain)
-template <int EPI, typename TC> struct EpiStores { static constexpr int n = EPI == EPI_GENERIC ? 0 : (EPI == EPI_GELU ? 16 : 8) * (sizeof(TC) == 2 ? 1 : 2); };
+template <int EPI, typename TC> struct EpiStores { static constexpr int n = EPI == EPI_GENERIC ? 0 : ((EPI == EPI_GELU || EPI == EPI_GELU_SG) ? 16 : 8) * (sizeof(TC) == 2 ? 1 : 2); };
 // one half (64 rows starting at tile row `rbase`) of the fused epilogue; thread owns columns 8*(tid&15).. and rows (tid>>4) + 16q
 template <int EPI, typename TC>
 __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid, int hp,
@@ -418,7 +425,7 @@ __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, 
     }
     return;
   }
-  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_PATCH;
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_GELU_SG || EPI == EPI_PATCH;
   constexpr bool HAS_RES = EPI == EPI_RES || EPI == EPI_RES_SCALE;
   const int nc = n < N ? n : N - 8;
   float bias[8];
@@ -433,7 +440,7 @@ __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, 
     if (EPI == EPI_PATCH) orow = (long)mc + mc / e.patch_rows + 1;
     off[q] = (size_t)orow * ldc + nc;
     if (HAS_RES) Vec8<TC>::ld((const TC*)e.res + off[q], rin[q]);
-    if (EPI == EPI_GELU_GRAD) Vec8<TC>::ld((const TC*)e.gelu_in + off[q], rin[q]);
+    if (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) Vec8<TC>::ld((const TC*)e.gelu_in + off[q], rin[q]);
     if (EPI == EPI_PATCH) Vec8<float>::ld(e.pos + (size_t)(1 + mc % e.patch_rows) * N + nc, rpos[q]);
     if (EPI == EPI_RES_SCALE) sc[q] = e.rowscale[mc / e.rows_per_sample];
   }
@@ -460,9 +467,24 @@ __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, 
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = gelu_fast(v[i]);
     }
+    if (EPI == EPI_GELU_SG) {   // one exp / rcp per element serves both gelu(u) (output) and gelu'(u) (saved for the backward)
+      float gp[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float cdf, pdf;
+        gelu_fast_parts(v[i], cdf, pdf);
+        gp[i] = cdf + v[i] * pdf;
+        v[i] *= cdf;
+      }
+      buf_store8<TC>(prs, off[q], ok, gp);
+    }
     if (EPI == EPI_GELU_GRAD) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] *= gelu_fast_grad(rin[q][i]);
+    }
+    if (EPI == EPI_MUL) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= rin[q][i];
     }
     if (EPI == EPI_RES_SCALE) {
 #pragma unroll
@@ -733,8 +755,8 @@ static int epi_kind(const GemmEpi& e) {
   int extras = (e.res != nullptr) + (e.preact != nullptr) + (e.gelu_in != nullptr) + (e.patch_rows > 0);
   if (extras > 1) return EPI_GENERIC;
   if (e.patch_rows > 0) return e.bias ? EPI_PATCH : EPI_GENERIC;
-  if (e.preact) return (e.bias && !e.rowscale) ? EPI_GELU : EPI_GENERIC;
-  if (e.gelu_in) return (!e.bias && !e.rowscale) ? EPI_GELU_GRAD : EPI_GENERIC;
+  if (e.preact) return (e.bias && !e.rowscale) ? (e.gelu_saved_grad ? EPI_GELU_SG : EPI_GELU) : EPI_GENERIC;
+  if (e.gelu_in) return (!e.bias && !e.rowscale) ? (e.gelu_saved_grad ? EPI_MUL : EPI_GELU_GRAD) : EPI_GENERIC;
   if (e.res) return !e.bias ? EPI_GENERIC : (e.rowscale ? EPI_RES_SCALE : EPI_RES);
   if (e.rowscale) return EPI_GENERIC;
   return e.bias ? EPI_BIAS : EPI_PLAIN;
@@ -747,9 +769,9 @@ static int launch_gemm(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, l
   const int k = epi_kind(epi);
   if (AM == KC && BMo == KC && sizeof(TC) == 2) {   // forward linears
     switch (k) { case EPI_BIAS: GO(EPI_BIAS); case EPI_RES: GO(EPI_RES); case EPI_RES_SCALE: GO(EPI_RES_SCALE); case EPI_GELU: GO(EPI_GELU);
-                 case EPI_PATCH: GO(EPI_PATCH); case EPI_PLAIN: GO(EPI_PLAIN); }
+                 case EPI_PATCH: GO(EPI_PATCH); case EPI_PLAIN: GO(EPI_PLAIN); case EPI_GELU_SG: GO(EPI_GELU_SG); }
   } else if (AM == KC && BMo == KR && sizeof(TC) == 2) {   // dX
-    switch (k) { case EPI_PLAIN: GO(EPI_PLAIN); case EPI_GELU_GRAD: GO(EPI_GELU_GRAD); case EPI_BIAS: GO(EPI_BIAS); }
+    switch (k) { case EPI_PLAIN: GO(EPI_PLAIN); case EPI_GELU_GRAD: GO(EPI_GELU_GRAD); case EPI_BIAS: GO(EPI_BIAS); case EPI_MUL: GO(EPI_MUL); }
   } else {
     switch (k) { case EPI_PLAIN: GO(EPI_PLAIN); case EPI_BIAS: GO(EPI_BIAS); }
   }

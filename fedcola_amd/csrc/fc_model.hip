@@ -442,7 +442,8 @@ static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int
     { GemmEpi e; e.bias = P + b.proj.b; e.res = t.x[l]; e.rowscale = dp_ptr(m, w.droppath, i, l, 0, B); e.rows_per_sample = N;
       FC_TRY(c.gemm_fwd(L.o, c.W(b.proj.w), L.xmid, M, D, D, e)); }
     FC_TRY(fc_layernorm_fwd(c.dt, L.xmid, P + b.n2w, P + b.n2b, L.h2, L.mean2, L.rstd2, M, D, 1e-5f, c.s));
-    { GemmEpi e; e.bias = P + b.fc1.b; e.preact = L.u; FC_TRY(c.gemm_fwd(L.h2, c.W(b.fc1.w), L.gact, M, Hd, D, e)); }
+    { GemmEpi e; e.bias = P + b.fc1.b; e.preact = L.u; e.gelu_saved_grad = (c.dt == FC_BF16);   // bf16: L.u holds gelu'(u)
+      FC_TRY(c.gemm_fwd(L.h2, c.W(b.fc1.w), L.gact, M, Hd, D, e)); }
     { GemmEpi e; e.bias = P + b.fc2.b; e.res = L.xmid; e.rowscale = dp_ptr(m, w.droppath, i, l, 1, B); e.rows_per_sample = N;
       FC_TRY(c.gemm_fwd(L.gact, c.W(b.fc2.w), t.x[l + 1], M, D, Hd, e)); }
   }
@@ -565,7 +566,7 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
     const void* dm = dx;
     if (s2) { FC_TRY(rowscale(c.dt, dx, L.gdm, s2, N, M, D, c.s)); dm = L.gdm; }
     FC_TRY(linear_bwd_params(c, b.fc2, dm, L.gact, M, grads));
-    { GemmEpi e; e.gelu_in = L.u; FC_TRY(c.gemm_dx(dm, c.W(b.fc2.w), L.gdu, M, D, Hd, e)); }                  // du = (dm.W2) * gelu'(u)
+    { GemmEpi e; e.gelu_in = L.u; e.gelu_saved_grad = (c.dt == FC_BF16); FC_TRY(c.gemm_dx(dm, c.W(b.fc2.w), L.gdu, M, D, Hd, e)); }                  // du = (dm.W2) * gelu'(u)
     FC_TRY(linear_bwd_params(c, b.fc1, L.gdu, L.h2, M, grads));
     const size_t lnp = (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D;
     { GemmEpi e; FC_TRY(c.gemm_dx(L.gdu, c.W(b.fc1.w), t.dh, M, Hd, D, e)); }                                  // dh2
