@@ -66,14 +66,27 @@ def gemm_roofline(steps=50):
     ms = e0.elapsed_time(e1) / steps
     flops = 2.0 * M * N * K
     achieved = flops / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="k_gemm_mfma<NT> fc1 12608x1536x384 bf16", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS,
-                unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None, us_per_launch=round(ms * 1e3, 2))
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "roofline_pmc.json")   # FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this launch
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+    alg_bytes = 2.0 * (M * K + N * K + M * N)
+    return dict(bound="mfma", kernel="k_gemm_mfma<NT,bias> fc1 shape 12608x1536x384 bf16 (dominant kernel family of the step)",
+                achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
+                traffic=traffic, us_per_launch=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
+                algorithmic_bytes_per_launch=alg_bytes, hbm_frac=round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
 
 
-def cpu_baseline(B, seq, vocab, steps=2):
-    """The oracle's explicit fp32 client step on the host cores (kind 'port'): bounded sample of the same workload."""
+def cpu_baseline_child(B, seq, vocab, steps):
+    """Runs in a CHILD process (no GPU touched): the oracle's explicit fp32 client step on the host cores."""
     from oracle import mome_oracle as O
     from fedcola_amd.mome import create_model
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    threads = max(1, min(cores, 64))          # torch CPU GEMMs stop scaling (and spin-wait badly) far below 256 threads
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     a = Args()
     a.precision = "fp32"
@@ -81,16 +94,37 @@ def cpu_baseline(B, seq, vocab, steps=2):
     p = {k: v.clone() for k, v in m.state_dict().items()}
     cfg = O.OracleCfg(D=384, depth=12, heads=6, vocab=vocab, max_text_len=seq)
     img, ids = make_batch(B, seq, vocab, 0, "cpu")
-    cores = os.cpu_count()
-    torch.set_num_threads(cores)
     state = dict(step=0, m={}, v={})
     O.client_step(p, cfg, ("img+txt", img, ids), state, lr=1e-4)     # warm-up
+    best = None
+    for th in sorted({t for t in (16, 32, 64) if t <= max(16, threads)}):   # torch CPU GEMMs at these sizes do not scale to every core
+        torch.set_num_threads(th)
+        t0 = time.perf_counter()
+        O.client_step(p, cfg, ("img+txt", img, ids), state, lr=1e-4)
+        d = time.perf_counter() - t0
+        if best is None or d < best[0]:
+            best = (d, th)
+    threads = best[1]
+    torch.set_num_threads(threads)
     t0 = time.perf_counter()
     for _ in range(steps):
         O.client_step(p, cfg, ("img+txt", img, ids), state, lr=1e-4)
     dt = (time.perf_counter() - t0) / steps
-    return dict(value=round(B / dt, 2), unit="img-txt pairs/s", cores=cores, kind="port",
-                sample=f"{steps} timed + 1 warm-up fp32 steps of the same B={B} ViT-S workload (oracle/mome_oracle.py, torch CPU ops)")
+    print(json.dumps(dict(value=round(B / dt, 2), unit="img-txt pairs/s", cores=threads, kind="port",
+                          sample=f"{steps} timed + 1 warm-up fp32 steps of the same B={B} ViT-S workload by oracle/mome_oracle.py "
+                                 f"(torch CPU ops, {threads} threads; host reports {os.cpu_count()} logical CPUs)")), flush=True)
+
+
+def cpu_baseline(B, seq, vocab, steps=2, timeout=240):
+    """Bounded CPU baseline in a child process started BEFORE this process touches the GPU."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--batch", str(B), "--steps", str(steps)],
+                             capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if line else dict(value=None, unit="img-txt pairs/s", kind="port", sample="child failed: " + out.stderr[-300:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="img-txt pairs/s", kind="port", cores=None, sample=f"CPU baseline exceeded {timeout}s and was skipped")
 
 
 def main():
@@ -102,10 +136,17 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_baseline_child:
+        cpu_baseline_child(a.batch, Args.seq_len, Args.vocab_size, min(a.steps, 3))
+        return
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    cpu_base = None
+    if world == 1 and not a.no_cpu_baseline:
+        cpu_base = cpu_baseline(a.batch, Args.seq_len, Args.vocab_size)      # before any GPU call in this process
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -136,10 +177,23 @@ def main():
         _lib.check(L.fc_client_step(model._handle.h, P(model.flat), P(grads), P(m1), P(m2), P(model._wc_or_flat()), P(img), P(ids), None,
                                     B, seq, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, step_no[0], P(lossbuf), P(ws), ws.numel(), sp))
 
+    # FedAvg aggregation of the `world` concurrent clients through the product path (fedcola_amd/aggregate.py): host-computed
+    # coefficient table + closed-form weights -> one HIP blend kernel per rank -> one RCCL all-reduce over xGMI
+    plan = None
+    if world > 1:
+        from fedcola_amd import aggregate as agg
+        import copy
+        ids = list(range(world))
+        keys = list(model.required_params().keys())
+        coef = {k: {i: 1.0 / world for i in ids} for k in keys}            # equal client sizes, scope 'dataset'
+        plan = agg.build_plan(model, ids, coef, {i: model.segments for i in ids})
+        global_model = copy.deepcopy(model)
+
     def aggregate():
-        if world > 1:   # FedAvg with equal client sizes: pre-weight 1/world, all-reduce(sum) over xGMI
-            model.flat.data.mul_(1.0 / world)
-            dist.all_reduce(model.flat.data)
+        if world > 1:
+            agg.aggregate(global_model, plan, {rank: model.flat.data}, rank=rank, world=world)
+            model.flat.data.copy_(global_model.flat.data)                  # next round's download(): device-to-device
+            model._bump()
 
     def barrier():
         if world > 1:
@@ -172,8 +226,8 @@ def main():
                    step_mfma_frac=round(pairs * PAIR_GFLOP / 1e3 / (world * PEAK_BF16_TFLOPS), 4), last_loss=round(loss, 4))
         if not a.no_roofline:
             out["roofline"] = gemm_roofline()
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, seq, args.vocab_size)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

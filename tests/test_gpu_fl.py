@@ -155,3 +155,25 @@ def test_plumbing_config0_two_img_clients_fedavg():
     assert torch.isfinite(srv.global_models["CIFAR100"].flat.data).all()
     assert (srv.global_models["CIFAR100"].flat.data - w0).abs().max() > 0
     assert abs(srv.curr_lr - 1e-4 * 0.99 ** 2) < 1e-12
+
+
+def test_hip_partials_of_two_emulated_ranks_sum_to_the_full_blend():
+    """The per-rank HIP partials (rank 0 carries w_g*g) add up to the single-process blend: what the RCCL all-reduce computes."""
+    from fedcola_amd import aggregate as agg
+    rec = G.load("agg.json")[1]
+    srv = H.make_server(rec, device="cuda")
+    ids = rec["ids"]
+    sizes = {i: len(srv.clients[i]) for i in ids}
+    ds = "Flickr30k"
+    gm = srv.global_models[ds]
+    keys = list(gm.required_params().keys())
+    coef = agg.mixing_coefficients(keys, srv.param_scope, sizes, srv.clients, dataset=ds, task="rtv", modality="img+txt",
+                                   out_modality_scale=1, args=srv.args)
+    segs = {i: srv._client_upload_segments(srv.clients[i]) for i in ids}
+    plan = agg.build_plan(gm, ids, coef, segs)
+    flats = {i: srv.clients[i].model.flat.data for i in ids}
+    full = agg.hip_local_partial(plan, gm.flat.data, flats, include_global=True)
+    r0 = agg.hip_local_partial(plan, gm.flat.data, {i: flats[i] for p, i in enumerate(ids) if p % 2 == 0}, include_global=True)
+    r1 = agg.hip_local_partial(plan, gm.flat.data, {i: flats[i] for p, i in enumerate(ids) if p % 2 == 1}, include_global=False)
+    assert (r0 + r1 - full).abs().max() <= 1e-6
+    assert full.abs().max() > 0
