@@ -44,13 +44,23 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   uint4 u = make_uint4(f2bf2(a[0], a[1]), f2bf2(a[2], a[3]), f2bf2(b[0], b[1]), f2bf2(b[2], b[3]));
   return *(bf16x8*)&u;
 }
-// stage a [N][64] slice (row stride ld elements) into a swizzled LDS tile of npad rows (zero rows past N)
-__device__ __forceinline__ void stage_tile(char* T, const bf16_t* __restrict__ src, long ld, int N, int npad, int tid) {
-  for (int idx = tid; idx < npad * 8; idx += 256) {
-    int row = idx >> 3, c = idx & 7;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (row < N) v = *(const uint4*)(src + (size_t)row * ld + c * 8);
-    *(uint4*)(T + at_off(row, c)) = v;
+// stage a [N][64] slice (row stride ld elements) into a swizzled LDS tile of NP rows (zero rows past N).  All global loads
+// of the tile are issued before the first LDS write (clamped row + select instead of a branch), so the staging pays ONE
+// memory round trip instead of one per 256-thread sweep.
+template <int NP>
+__device__ __forceinline__ void stage_tile(char* T, const bf16_t* __restrict__ src, long ld, int N, int tid) {
+  constexpr int IT = NP * 8 / 256;
+  uint4 v[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+    int rc = row < N ? row : N - 1;
+    v[i] = *(const uint4*)(src + (size_t)rc * ld + c * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+    *(uint4*)(T + at_off(row, c)) = row < N ? v[i] : make_uint4(0u, 0u, 0u, 0u);
   }
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
@@ -67,8 +77,8 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(const bf16_t* __restrict_
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
-  stage_tile(Ks, base + Dm, D3, N, NP, tid);
-  stage_tile(Vs, base + 2 * Dm, D3, N, NP, tid);
+  stage_tile<NP>(Ks, base + Dm, D3, N, tid);
+  stage_tile<NP>(Vs, base + 2 * Dm, D3, N, tid);
   __syncthreads();
   const int nqb = (N + 15) >> 4;
   for (int qb = wave; qb < nqb; qb += 4) {
@@ -118,9 +128,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(const bf16_t* __restrict_
       bf16_t* orow = o + ((size_t)b * N + qrow) * Dm + h * 64 + 4 * g;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        ushort4 pk;
-        pk.x = f2bf(oacc[db][0] * inv); pk.y = f2bf(oacc[db][1] * inv); pk.z = f2bf(oacc[db][2] * inv); pk.w = f2bf(oacc[db][3] * inv);
-        *(ushort4*)(orow + db * 16) = pk;
+        *(uint2*)(orow + db * 16) = make_uint2(f2bf2(oacc[db][0] * inv, oacc[db][1] * inv), f2bf2(oacc[db][2] * inv, oacc[db][3] * inv));
       }
       if (g == 0) lse[((size_t)b * H + h) * N + qrow] = m + __logf(sum);
     }
@@ -159,8 +167,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
   const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
   const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
-  stage_tile(Ks, base + Dm, D3, N, NP, tid);
-  stage_tile(Vs, base + 2 * Dm, D3, N, NP, tid);
+  stage_tile<NP>(Ks, base + Dm, D3, N, tid);
+  stage_tile<NP>(Vs, base + 2 * Dm, D3, N, tid);
   __syncthreads();
   bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
   const int nqb = (N + 15) >> 4;
@@ -198,18 +206,15 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
 #pragma unroll
         for (int x = 0; x < 4; ++x) ds[hh][x] = __expf(st[x] * scale - lq) * (dpt[x] - dl);
       }
-      bf16x8 af = pack8(ds[0], ds[1]);
+      bf16x8 bfg = pack8(ds[0], ds[1]);                                 // B[k = key(8g+j)][col = q = cl]
 #pragma unroll
-      for (int db = 0; db < 4; ++db) dq[db] = MFMA(af, tr_frag(Ks, 32 * ss, db * 16, lane), dq[db]);   // dQ[q = 4g+x][d = 16db+cl]
+      for (int db = 0; db < 4; ++db) dq[db] = MFMA(tr_frag(Ks, 32 * ss, db * 16, lane), bfg, dq[db]);   // dQ^T[d = 16db+4g+x][q = cl]
     }
+    if (qrow < N) {   // a lane owns 4 consecutive head dims of its query row: 8-byte stores
+      bf16_t* p = dbase + (size_t)qrow * D3 + 4 * g;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      int row = qb * 16 + 4 * g + x;
-      if (row < N) {
-        bf16_t* p = dbase + (size_t)row * D3 + cl;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) p[db * 16] = f2bf(dq[db][x] * scale);
-      }
+      for (int db = 0; db < 4; ++db)
+        *(uint2*)(p + db * 16) = make_uint2(f2bf2(dq[db][0] * scale, dq[db][1] * scale), f2bf2(dq[db][2] * scale, dq[db][3] * scale));
     }
   }
 }
@@ -230,23 +235,33 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
   const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
   const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
-  stage_tile(Qs, base, D3, N, NP, tid);
+  stage_tile<NP>(Qs, base, D3, N, tid);
   // stage dO and form delta = rowsum(dO * O): a row's 8 chunks sit in 8 consecutive lanes
-  for (int idx = tid; idx < NP * 8; idx += 256) {
-    int row = idx >> 3, c = idx & 7;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u), ov = make_uint4(0u, 0u, 0u, 0u);
-    if (row < N) {
-      v = *(const uint4*)(dobase + (size_t)row * Dm + c * 8);
-      ov = *(const uint4*)(obase + (size_t)row * Dm + c * 8);
+  {
+    constexpr int IT = NP * 8 / 256;
+    uint4 dv_[IT], ov_[IT];
+    float ls_[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+      int rc = row < N ? row : N - 1;
+      dv_[i] = *(const uint4*)(dobase + (size_t)rc * Dm + c * 8);
+      ov_[i] = *(const uint4*)(obase + (size_t)rc * Dm + c * 8);
+      ls_[i] = lse[((size_t)b * H + h) * N + rc];
     }
-    *(uint4*)(Ds + at_off(row, c)) = v;
-    float d = dot8(*(bf16x8*)&v, *(bf16x8*)&ov);
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
-    if (c == 0) {
-      del_s[row] = d;
-      lse_s[row] = row < N ? lse[((size_t)b * H + h) * N + row] : 1e30f;   // padded queries: P = exp(. - 1e30) = 0
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+      uint4 v = row < N ? dv_[i] : make_uint4(0u, 0u, 0u, 0u);
+      *(uint4*)(Ds + at_off(row, c)) = v;
+      float d = dot8(*(bf16x8*)&v, *(bf16x8*)&ov_[i]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      if (c == 0) {
+        del_s[row] = d;
+        lse_s[row] = row < N ? ls_[i] : 1e30f;   // padded queries: P = exp(. - 1e30) = 0
+      }
     }
   }
   __syncthreads();
@@ -284,21 +299,20 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
           dS[hh][x] = p * (dpa[x] - dl[x]);
         }
       }
-      bf16x8 pa = pack8(P[0], P[1]), dsa = pack8(dS[0], dS[1]);          // A[row = key = cl][k = q(8g+j)]
+      bf16x8 pa = pack8(P[0], P[1]), dsa = pack8(dS[0], dS[1]);          // B[k = q(8g+j)][col = key = cl]
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        dv[db] = MFMA(pa, tr_frag(Ds, 32 * qp, db * 16, lane), dv[db]);  // dV[key = 4g+x][d = 16db+cl]
-        dk[db] = MFMA(dsa, tr_frag(Qs, 32 * qp, db * 16, lane), dk[db]); // dK[key][d]
+        dv[db] = MFMA(tr_frag(Ds, 32 * qp, db * 16, lane), pa, dv[db]);  // dV^T[d = 16db+4g+x][key = cl]
+        dk[db] = MFMA(tr_frag(Qs, 32 * qp, db * 16, lane), dsa, dk[db]); // dK^T[d][key]
       }
     }
+    if (krow < N) {   // a lane owns 4 consecutive head dims of its key row: 8-byte stores
+      bf16_t* pk = dbase + (size_t)krow * D3 + Dm + 4 * g;
+      bf16_t* pv = dbase + (size_t)krow * D3 + 2 * Dm + 4 * g;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      int row = f * 16 + 4 * g + x;
-      if (row < N) {
-        bf16_t* pk = dbase + (size_t)row * D3 + Dm + cl;
-        bf16_t* pv = dbase + (size_t)row * D3 + 2 * Dm + cl;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) { pk[db * 16] = f2bf(dk[db][x] * scale); pv[db * 16] = f2bf(dv[db][x]); }
+      for (int db = 0; db < 4; ++db) {
+        *(uint2*)(pk + db * 16) = make_uint2(f2bf2(dk[db][0] * scale, dk[db][1] * scale), f2bf2(dk[db][2] * scale, dk[db][3] * scale));
+        *(uint2*)(pv + db * 16) = make_uint2(f2bf2(dv[db][0], dv[db][1]), f2bf2(dv[db][2], dv[db][3]));
       }
     }
   }
