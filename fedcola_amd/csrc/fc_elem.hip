@@ -374,43 +374,73 @@ int fc_txt_embed_fwd(int dt, const int64_t* ids, const float* word, const float*
   return 0;
 }
 
-// de = LNbwd(dy) per row; dword[id] += de (id != 0: padding_idx row gets no grad); dpos[n] += de; dtype[0] += de; dg/db
+// de = LNbwd(dy) per row; dword[id] += de (id != 0: padding_idx row gets no grad); dpos[n] += de; dtype[0] += de; dg/db.
+// One block per token position n: its 4 waves walk the batch, keep dpos[n] / dtype / dgamma / dbeta partial sums in
+// registers, reduce across the waves in LDS, and issue one add per column per block (only the word-row scatter stays a
+// per-row atomic).
+#define TEB_MAXV 16
 template <typename T>
 __global__ void __launch_bounds__(256) k_txt_embed_bwd(const T* __restrict__ dy, const int64_t* __restrict__ ids, const float* __restrict__ word,
                                                        const float* __restrict__ pos, const float* __restrict__ type,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ g, float* dword, float* dpos, float* dtype, float* dg,
                                                        float* db, int B, int N, int D, int vocab) {
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= B * N) return;
-  int n = row % N;
-  long id = clamp_id(ids[row], vocab);
-  const float* w = word + (size_t)id * D;
+  __shared__ float red[3][4][64 * TEB_MAXV > 1024 ? 1024 : 64 * TEB_MAXV];
+  const int n = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float* pp = pos + (size_t)n * D;
-  float mu = mean[row], rs = rstd[row];
-  const T* dyr = dy + (size_t)row * D;
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = lane; i < D; i += 64) {
-    float d = Io<T>::ld(dyr, i), xh = (w[i] + type[i] + pp[i] - mu) * rs;
-    s1 += d * g[i]; s2 += d * g[i] * xh;
+  float ade[TEB_MAXV], agm[TEB_MAXV], abt[TEB_MAXV];
+#pragma unroll
+  for (int t = 0; t < TEB_MAXV; ++t) { ade[t] = 0.f; agm[t] = 0.f; abt[t] = 0.f; }
+  for (int bi = wave; bi < B; bi += 4) {
+    const int row = bi * N + n;
+    const long id = clamp_id(ids[row], vocab);
+    const float* w = word + (size_t)id * D;
+    const float mu = mean[row], rs = rstd[row];
+    const T* dyr = dy + (size_t)row * D;
+    float d[TEB_MAXV], xh[TEB_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < TEB_MAXV; ++t) {
+      int i = lane + 64 * t;
+      d[t] = 0.f; xh[t] = 0.f;
+      if (i < D) {
+        d[t] = Io<T>::ld(dyr, i);
+        xh[t] = (w[i] + type[i] + pp[i] - mu) * rs;
+        s1 += d[t] * g[i]; s2 += d[t] * g[i] * xh[t];
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int t = 0; t < TEB_MAXV; ++t) {
+      int i = lane + 64 * t;
+      if (i < D) {
+        float de = rs * (d[t] * g[i] - s1 - xh[t] * s2);
+        if (id != 0) atomicAdd(dword + (size_t)id * D + i, de);
+        ade[t] += de; agm[t] += d[t] * xh[t]; abt[t] += d[t];
+      }
+    }
   }
-  s1 = wave_sum(s1) / (float)D;
-  s2 = wave_sum(s2) / (float)D;
-  for (int i = lane; i < D; i += 64) {
-    float d = Io<T>::ld(dyr, i), xh = (w[i] + type[i] + pp[i] - mu) * rs;
-    float de = rs * (d * g[i] - s1 - xh * s2);
-    if (id != 0) atomicAdd(dword + (size_t)id * D + i, de);
+#pragma unroll
+  for (int t = 0; t < TEB_MAXV; ++t) {
+    int i = lane + 64 * t;
+    if (i < D) { red[0][wave][i] = ade[t]; red[1][wave][i] = agm[t]; red[2][wave][i] = abt[t]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) {
+    float de = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
     atomicAdd(dpos + (size_t)n * D + i, de);
     atomicAdd(dtype + i, de);
-    atomicAdd(dg + i, d * xh);
-    atomicAdd(db + i, d);
+    atomicAdd(dg + i, red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+    atomicAdd(db + i, red[2][0][i] + red[2][1][i] + red[2][2][i] + red[2][3][i]);
   }
 }
 int fc_txt_embed_bwd(int dt, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type, const float* mean,
                      const float* rstd, const float* g, float* dword, float* dpos, float* dtype, float* dg, float* db, int B, int N, int D,
                      int vocab, hipStream_t s) {
-  DISPATCH_DT(dt, hipLaunchKernelGGL(k_txt_embed_bwd<T>, dim3(fc_cdiv((long)B * N, 4)), dim3(256), 0, s, (const T*)dy, ids, word, pos, type,
-                                     mean, rstd, g, dword, dpos, dtype, dg, db, B, N, D, vocab));
+  FC_REQUIRE(D <= 64 * TEB_MAXV, "txt_embed_bwd: D=%d > %d unsupported", D, 64 * TEB_MAXV);
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_txt_embed_bwd<T>, dim3(N), dim3(256), 0, s, (const T*)dy, ids, word, pos, type, mean, rstd, g, dword,
+                                     dpos, dtype, dg, db, B, N, D, vocab));
   FC_LAUNCH_CHECK();
   return 0;
 }
@@ -522,21 +552,49 @@ __global__ void __launch_bounds__(256) k_con_dl(const float* __restrict__ L, con
     dL[idx] = (0.5f / (float)B) * (expf(l - lse_r[i]) + expf(l - lse_c[j]) - (i == j ? 2.0f : 0.0f));
   }
 }
+// L[i][j] = tau * <a_i, b_j>: one block per row i, thread t -> column t>>2, quarter t&3 of the feature range
+__global__ void __launch_bounds__(256) k_con_logits(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ L, int B, int D, float tau) {
+  const int i = blockIdx.x, q = threadIdx.x & 3;
+  const float* ar = a + (size_t)i * D;
+  for (int j = threadIdx.x >> 2; j < B; j += 64) {
+    const float* br = b + (size_t)j * D;
+    float s = 0.f;
+    for (int d = q; d < D; d += 4) s = fmaf(ar[d], br[d], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (q == 0) L[(size_t)i * B + j] = tau * s;
+  }
+}
+// blocks [0,B): da_i = tau * sum_j dL_ij b_j ; blocks [B,2B): db_j = tau * sum_i dL_ij a_i ; dL formed on the fly
+__global__ void __launch_bounds__(256) k_con_grads(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ L,
+                                                   const float* __restrict__ lse_r, const float* __restrict__ lse_c, float* __restrict__ da,
+                                                   float* __restrict__ db, int B, int D, float tau) {
+  extern __shared__ float w[];   // dL row / column
+  const bool isrow = blockIdx.x < (unsigned)B;
+  const int r = isrow ? blockIdx.x : blockIdx.x - B;
+  for (int o = threadIdx.x; o < B; o += 256) {
+    int i = isrow ? r : o, j = isrow ? o : r;
+    float l = L[(size_t)i * B + j];
+    w[o] = (0.5f / (float)B) * (expf(l - lse_r[i]) + expf(l - lse_c[j]) - (i == j ? 2.0f : 0.0f)) * tau;
+  }
+  __syncthreads();
+  const float* src = isrow ? b : a;
+  float* dst = (isrow ? da : db) + (size_t)r * D;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int o = 0; o < B; ++o) s = fmaf(w[o], src[(size_t)o * D + d], s);
+    dst[d] = s;
+  }
+}
 int fc_contrastive_fwd_bwd(const float* a, const float* b, int B, int D, float tau, float* scratch, float* lossbuf, float* da, float* db,
                            hipStream_t s) {
   float* L = scratch;
-  float* dL = scratch + (size_t)B * B;
-  float* lse_r = dL + (size_t)B * B;
+  float* lse_r = scratch + 2 * (size_t)B * B;
   float* lse_c = lse_r + B;
-  GemmEpi e;
-  e.alpha = tau;
-  FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, a, D, 1, b, 1, D, L, B, B, B, D, e, s));                // L = tau * a b^T
+  hipLaunchKernelGGL(k_con_logits, dim3(B), dim3(256), 0, s, a, b, L, B, D, tau);
   hipLaunchKernelGGL(k_con_lse, dim3(2 * B), dim3(64), 0, s, L, lse_r, lse_c, lossbuf, B);
+  hipLaunchKernelGGL(k_con_grads, dim3(2 * B), dim3(256), sizeof(float) * B, s, a, b, L, lse_r, lse_c, da, db, B, D, tau);
   FC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_con_dl, dim3(fc_cdiv((long)B * B, 256)), dim3(256), 0, s, L, lse_r, lse_c, dL, B);
-  FC_LAUNCH_CHECK();
-  FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, dL, B, 1, b, D, 1, da, D, B, D, B, e, s));              // da = tau * dL b
-  FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, dL, 1, B, a, D, 1, db, D, B, D, B, e, s));              // db = tau * dL^T a
   return 0;
 }
 

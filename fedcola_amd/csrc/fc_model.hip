@@ -686,7 +686,7 @@ extern "C" int fc_ce_loss_fwd_bwd(const float* logits, const int64_t* y, int32_t
 }
 
 static int adamw_ranges(const fc_model* m, float* p, float* g, float* mm, float* vv, float lr, float b1, float b2, float eps, float wd, int step,
-                        hipStream_t s) {
+                        hipStream_t s, bf16_t* shadow = nullptr) {
   // contiguous runs of trainable segments (padding included) -> one launch each; frozen segments are skipped like torch
   size_t i = 0, n = m->segs.size();
   while (i < n) {
@@ -695,7 +695,7 @@ static int adamw_ranges(const fc_model* m, float* p, float* g, float* mm, float*
     while (j + 1 < n && m->segs[j + 1].trainable) ++j;
     int64_t beg = m->segs[i].offset;
     int64_t end = (j + 1 < n) ? m->segs[j + 1].offset : m->total;
-    FC_TRY(fc_adamw(p + beg, g + beg, mm + beg, vv + beg, (size_t)(end - beg), lr, b1, b2, eps, wd, step, nullptr, 0, s));
+    FC_TRY(fc_adamw(p + beg, g + beg, mm + beg, vv + beg, (size_t)(end - beg), lr, b1, b2, eps, wd, step, shadow ? shadow + beg : nullptr, 0, s));
     i = j + 1;
   }
   return 0;
@@ -735,8 +735,16 @@ extern "C" int fc_client_step(const fc_model_t* m, float* params, float* grads, 
     (i == 0 ? d0 : d1) = w.dout[i];
   }
   FC_TRY(backward_impl(m, params, wc, d0, d1, grads, w, s));
-  FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s));
-  if (m->need_wc) FC_TRY(fc_prepare_weights(m, params, wc, stream));
+  // compute weights for the next step: without re-param linears and with every segment trainable the bf16 shadow is written
+  // by the AdamW kernel itself (one pass over the parameters instead of two)
+  bool has_aux = false, all_trainable = true;
+  for (const fc_segment& sg : m->segs) {
+    if (strstr(sg.name, "aux_weight")) has_aux = true;
+    if (!sg.trainable) all_trainable = false;
+  }
+  const bool fuse_shadow = m->need_wc && m->dt == FC_BF16 && !has_aux && all_trainable;
+  FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s, fuse_shadow ? (bf16_t*)wc : nullptr));
+  if (m->need_wc && !fuse_shadow) FC_TRY(fc_prepare_weights(m, params, wc, stream));
   return 0;
 }
 
