@@ -96,7 +96,9 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
                                                   const float* __restrict__ rstd, const float* __restrict__ g, const T* res, T* dx,
                                                   float* __restrict__ dg, float* __restrict__ db, int M, int D, int rows_per_block,
                                                   float* __restrict__ partial) {
-  __shared__ float red[2][4][1024];
+  extern __shared__ float red_dyn[];   // [2][4][D]: sized by the launch, so that narrow models keep many blocks per CU
+  float (*red)[4][1] = nullptr; (void)red;
+#define RED(a, w, i) red_dyn[((a) * 4 + (w)) * D + (i)]
   int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nc = D >> 3;
   float ag[LNV_MAXC][8], ab[LNV_MAXC][8], gg[LNV_MAXC][8];
@@ -152,22 +154,23 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
     int c = lane + 64 * t;
     if (c < nc) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { red[0][wave][c * 8 + i] = ag[t][i]; red[1][wave][c * 8 + i] = ab[t][i]; }
+      for (int i = 0; i < 8; ++i) { RED(0, wave, c * 8 + i) = ag[t][i]; RED(1, wave, c * 8 + i) = ab[t][i]; }
     }
   }
   __syncthreads();
   if (partial) {  // [block][dg(D) | db(D)], reduced later by k_ln_reduce_grouped (no same-address atomic storm)
     float* pp = partial + (size_t)blockIdx.x * 2 * D;
     for (int i = threadIdx.x; i < D; i += 256) {
-      pp[i] = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
-      pp[D + i] = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
+      pp[i] = RED(0, 0, i) + RED(0, 1, i) + RED(0, 2, i) + RED(0, 3, i);
+      pp[D + i] = RED(1, 0, i) + RED(1, 1, i) + RED(1, 2, i) + RED(1, 3, i);
     }
     return;
   }
   for (int i = threadIdx.x; i < D; i += 256) {
-    atomicAdd(dg + i, red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
-    atomicAdd(db + i, red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+    atomicAdd(dg + i, RED(0, 0, i) + RED(0, 1, i) + RED(0, 2, i) + RED(0, 3, i));
+    atomicAdd(db + i, RED(1, 0, i) + RED(1, 1, i) + RED(1, 2, i) + RED(1, 3, i));
   }
+#undef RED
 }
 
 // grouped reduction of the LayerNorm-backward partials: block (x = column chunk of 64, y = LN instance)
@@ -275,7 +278,7 @@ int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, c
   if (M <= 0) return 0;
   if (ln_vec_ok(dy, x, dx, res, D) && !((uintptr_t)g & 15)) {
     const int rpb = 16;
-    DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd_v<T>, dim3(fc_cdiv(M, rpb)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, g,
+    DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd_v<T>, dim3(fc_cdiv(M, rpb)), dim3(256), sizeof(float) * 8 * D, s, (const T*)dy, (const T*)x, mean, rstd, g,
                                        (const T*)res, (T*)dx, dg, db, M, D, rpb, partial));
     FC_LAUNCH_CHECK();
     return partial ? 1 : 0;   // 1: dg/db are pending in `partial` (caller queues the grouped reduction)
