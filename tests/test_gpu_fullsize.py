@@ -1,0 +1,61 @@
+"""Full-size parity on the GPU: mome_small_patch16 (ViT-S + 12x384 text tower, vocab 7732, 32-token captions), B=64 --
+BASELINE.json's config[1] -- one client step against the oracle on the same synthetic batch.
+fp32 mode: <= 1e-4 relative on features, loss and every gradient tensor; bf16 mode: the stated bf16 tolerance."""
+import pytest
+import torch
+
+import product_util as PU
+from oracle import mome_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MK = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=384, depth=12, num_heads=6,
+          vocab_size=7732, max_text_len=32)
+
+
+def _batch(B=64, seq=32, vocab=7732):
+    g = torch.Generator().manual_seed(1000)
+    img = (torch.randn(B, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1)
+    ids = torch.randint(1, vocab, (B, seq), generator=g)
+    lens = torch.randint(8, seq + 1, (B,), generator=g)
+    ids[torch.arange(seq)[None, :] >= lens[:, None]] = 0
+    return img, ids
+
+
+@pytest.fixture(scope="module")
+def oracle_result():
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    torch.manual_seed(5)
+    ref = M(**MK)                                   # reference default init (pos/cls zero) ...
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    for k in sd:                                    # ... with non-zero pos / cls so that their gradients are exercised
+        if "pos_embed" in k or "cls_token" in k:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.02
+    img, ids = _batch()
+    cfg = O.OracleCfg(D=384, depth=12, heads=6, vocab=7732, max_text_len=32)
+    p = {k: v.clone() for k, v in sd.items()}
+    outs, cache = O.forward(p, cfg, [img, ids], feat_out=True)
+    loss, da, db = O.contrastive_loss(outs[0], outs[1])
+    grads = O.backward(p, cfg, cache, [da, db])
+    return sd, img, ids, outs, float(loss), grads
+
+
+@pytest.mark.parametrize("prec,otol,gtol", [("fp32", 1e-4, 1e-4), ("bf16", 3e-2, 8e-2)])
+def test_vit_s_b64_step_vs_oracle(oracle_result, prec, otol, gtol):
+    sd, img, ids, outs_o, loss_o, grads_o = oracle_result
+    model = PU.build_product(MK, prec, sd)
+    model.train()
+    with torch.no_grad():
+        outs = model([img.cuda(), ids.cuda()], feat_out=True)
+    for o, oo in zip(outs, outs_o):
+        assert float((o.cpu() - oo).abs().max()) <= otol, "encoder outputs (unit-norm features)"
+    loss, grads, _ = PU.product_step(model, "img+txt", img, ids, None, 1e-4)
+    assert abs(loss - loss_o) <= max(otol, 1e-4) * max(1.0, abs(loss_o))
+    worst = ("", 0.0)
+    for k, go in grads_o.items():
+        scale = max(float(go.abs().max()), 1e-7)
+        rel = float((grads[k] - go).abs().max()) / scale
+        if rel > worst[1]:
+            worst = (k, rel)
+    assert worst[1] <= gtol, f"worst gradient tensor {worst}"
