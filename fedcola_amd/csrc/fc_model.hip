@@ -1,6 +1,7 @@
 // Host-side driver of the client step: parameter layout (reference state_dict order), workspace carving, and the
 // forward / backward / step launch sequences.  Everything is enqueued on the caller's stream; nothing allocates.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -49,7 +50,13 @@ struct fc_model {
   // the two towers are independent until the loss: the text tower runs on a side stream, forked/joined with events
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // weight gradients are launched in chunks (every few layers) on their own stream, under the rest of the backward
+  mutable hipStream_t dws = nullptr;
+  mutable hipEvent_t ev_dw_in = nullptr, ev_dw_out = nullptr;
   ~fc_model() {
+    if (dws) (void)hipStreamDestroy(dws);
+    if (ev_dw_in) (void)hipEventDestroy(ev_dw_in);
+    if (ev_dw_out) (void)hipEventDestroy(ev_dw_out);
     if (side) (void)hipStreamDestroy(side);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -336,6 +343,7 @@ struct Ctx {
   int dt;
   size_t es;
   std::vector<FcTnProblem>* defer = nullptr;   // non-null: weight/bias gradients are queued for the grouped launch
+  struct DwState* dw = nullptr;                // chunked early launches of the queued problems
   std::vector<FcLnReduce>* lnq = nullptr;      // non-null: LayerNorm dgamma/dbeta partials are queued likewise
   int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res, void* dx, float* dg,
              float* db, int M, int D, float* partial) const {
@@ -462,6 +470,11 @@ static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int
 }
 
 static int ensure_side(const fc_model* m) {
+  if (!m->dws) {
+    FC_CHECK_HIP(hipStreamCreateWithFlags(&m->dws, hipStreamNonBlocking));
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in, hipEventDisableTiming));
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_out, hipEventDisableTiming));
+  }
   if (!m->side) {
     FC_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
@@ -525,6 +538,49 @@ extern "C" int fc_forward(const fc_model_t* m, const float* params, const void* 
 }
 
 // ---------------------------------------------------------------- backward
+static int dw_flush_every() {
+  static int v = getenv("FC_DW_FLUSH") ? atoi(getenv("FC_DW_FLUSH")) : 2;
+  return v > 0 ? v : 2;
+}
+struct DwState {
+  size_t flushed = 0;     // problems [0, flushed) have been launched
+  int tiles = 0;
+  bool changed = false;   // some chunk differed from the cached table
+  FcTnProblem* dev = nullptr;
+  int max_probs = 0;
+};
+// launch the problems queued since the last flush as one grouped GEMM on the dW stream, ordered after everything enqueued so
+// far on this tower's stream (their dY / X operands are complete by then)
+static int flush_dw(const Ctx& c) {
+  if (!c.defer || !c.dw) return 0;
+  std::vector<FcTnProblem>& all = *c.defer;
+  DwState& st = *c.dw;
+  const size_t beg = st.flushed, n = all.size() - beg;
+  if (n == 0) return 0;
+  FC_REQUIRE((int)all.size() <= st.max_probs, "internal: too many deferred weight-gradient problems");
+  int tiles = 0;
+  for (size_t i = beg; i < all.size(); ++i) {
+    all[i].tile_start = tiles;
+    all[i].tiles_n = fc_cdiv(all[i].N, 128);
+    tiles += fc_cdiv(all[i].M, 128) * all[i].tiles_n;
+  }
+  const fc_model* m = c.m;
+  bool same = m->probs_dev == st.dev && m->probs_host.size() >= all.size() &&
+              memcmp(m->probs_host.data() + beg, all.data() + beg, n * sizeof(FcTnProblem)) == 0;
+  if (!same) {
+    FC_CHECK_HIP(hipStreamSynchronize(m->dws));   // an earlier launch may still be reading the table
+    if (m->probs_host.size() < all.size()) m->probs_host.resize(all.size());
+    memcpy(m->probs_host.data() + beg, all.data() + beg, n * sizeof(FcTnProblem));
+    m->probs_dev = st.dev;
+    FC_CHECK_HIP(hipMemcpyAsync(st.dev + beg, m->probs_host.data() + beg, n * sizeof(FcTnProblem), hipMemcpyHostToDevice, m->dws));
+  }
+  FC_CHECK_HIP(hipEventRecord(m->ev_dw_in, c.s));
+  FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in, 0));
+  FC_TRY(fc_gemm_tn_grouped(st.dev + beg, (int)n, tiles, m->dws));
+  st.flushed = all.size();
+  return 0;
+}
+
 static int weight_grad(const Ctx& c, const void* dY, const void* X, int M, int out, int in, float* dW, float* db) {
   if (c.defer) {
     FcTnProblem p{(const bf16_t*)dY, (const bf16_t*)X, dW, db, out, in, in, out, in, M, 0, 0};
@@ -581,6 +637,7 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
     FC_TRY(linear_bwd_params(c, b.qkv, L.gdqkv, L.h1, M, grads));
     { GemmEpi e; FC_TRY(c.gemm_dx(L.gdqkv, c.W(b.qkv.w), t.dh, M, 3 * D, D, e)); }                             // dh1
     FC_TRY(c.ln_bwd(t.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, L.gxmid, t.gx[l], grads + b.n1w, grads + b.n1b, M, D, t.ln_partial + (2 * l) * lnp));
+    if (l % dw_flush_every() == 0 && l > 0) FC_TRY(flush_dw(c));   // this chunk's weight gradients start now, under the remaining layers
   }
   const void* dx = t.gx[0];
   if (i == 0) {
@@ -591,6 +648,7 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
     FC_TRY(fc_txt_embed_bwd(c.dt, dx, w.ids, P + tp.word, P + tp.tpos, P + tp.ttype, t.emb_mean, t.emb_rstd, P + tp.lnw, grads + tp.word,
                             grads + tp.tpos, grads + tp.ttype, grads + tp.lnw, grads + tp.lnb, B, N, D, cf.vocab, c.s));
   }
+  FC_TRY(flush_dw(c));
   return 0;
 }
 
@@ -616,7 +674,14 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
   std::vector<FcTnProblem> probs;
   std::vector<FcLnReduce> lnq;
-  if (m->dt == FC_BF16) c.defer = &probs;   // all dW / db products of this backward go into one grouped MFMA launch
+  DwState dwst;
+  if (m->dt == FC_BF16) {   // dW / db products are queued and launched in grouped chunks on the dW stream
+    FC_TRY(ensure_side(m));
+    c.defer = &probs;
+    dwst.dev = w.probs;
+    dwst.max_probs = w.max_probs;
+    c.dw = &dwst;
+  }
   c.lnq = &lnq;
   const bool run0 = m->tw[0].present && d_out_img, run1 = m->tw[1].present && d_out_txt;
   if (run0 && run1) {
@@ -642,24 +707,9 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     }
     FC_TRY(fc_ln_reduce_grouped(w.lntab, (int)lnq.size(), m->cfg.dim, s));
   }
-  if (!probs.empty()) {
-    FC_REQUIRE((int)probs.size() <= w.max_probs, "internal: too many deferred weight-gradient problems");
-    int tiles = 0;
-    for (FcTnProblem& p : probs) {
-      p.tile_start = tiles;
-      p.tiles_n = fc_cdiv(p.N, 128);
-      tiles += fc_cdiv(p.M, 128) * p.tiles_n;
-    }
-    // the table only depends on buffer addresses and shapes: re-upload only when it changed
-    bool same = m->probs_dev == w.probs && m->probs_host.size() == probs.size() &&
-                memcmp(m->probs_host.data(), probs.data(), probs.size() * sizeof(FcTnProblem)) == 0;
-    if (!same) {
-      FC_CHECK_HIP(hipStreamSynchronize(s));   // the previous table may still be in use by an earlier launch
-      m->probs_host = probs;
-      m->probs_dev = w.probs;
-      FC_CHECK_HIP(hipMemcpyAsync(w.probs, m->probs_host.data(), probs.size() * sizeof(FcTnProblem), hipMemcpyHostToDevice, s));
-    }
-    FC_TRY(fc_gemm_tn_grouped(w.probs, (int)probs.size(), tiles, s));
+  if (!probs.empty()) {   // every chunk was launched by flush_dw; the main stream continues after the last one
+    FC_CHECK_HIP(hipEventRecord(m->ev_dw_out, m->dws));
+    FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
   }
   if (m->tw[0].present && d_out_img) FC_TRY(tower_reparam_grads(c, 0, grads));
   if (m->tw[1].present && d_out_txt) FC_TRY(tower_reparam_grads(c, 1, grads));
