@@ -52,10 +52,16 @@ struct fc_model {
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // weight gradients are launched in chunks (every few layers) on their own stream, under the rest of the backward
   mutable hipStream_t dws = nullptr;
-  mutable hipEvent_t ev_dw_in = nullptr, ev_dw_out = nullptr;
+  mutable hipEvent_t ev_dw_in = nullptr, ev_dw_in2 = nullptr, ev_dw_out = nullptr;
+  // second micro-batch of the image tower
+  mutable hipStream_t mbs = nullptr;
+  mutable hipEvent_t ev_mb_join = nullptr;
   ~fc_model() {
     if (dws) (void)hipStreamDestroy(dws);
     if (ev_dw_in) (void)hipEventDestroy(ev_dw_in);
+    if (ev_dw_in2) (void)hipEventDestroy(ev_dw_in2);
+    if (mbs) (void)hipStreamDestroy(mbs);
+    if (ev_mb_join) (void)hipEventDestroy(ev_mb_join);
     if (ev_dw_out) (void)hipEventDestroy(ev_dw_out);
     if (side) (void)hipStreamDestroy(side);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -205,6 +211,7 @@ struct Ws {
   FcLnReduce* lntab;    // device array for the grouped LayerNorm-gradient reduction
   int max_probs, max_ln;
   int B, n_txt, feat_out;
+  int dp_stride = 0, dp_off = 0;   // drop-path table: samples per row / first sample of this (micro-batch) view
   const float* droppath;
   const int64_t* ids;
   size_t bytes;
@@ -283,15 +290,63 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
     t.dh = bp.take((size_t)t.M * D * es);
     t.dO = bp.take((size_t)t.M * D * es);
     t.delta = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * t.N);
-    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)2 * c.depth * fc_layernorm_bwd_partial_blocks(t.M) * 2 * D);
+    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)2 * 2 * c.depth * fc_layernorm_bwd_partial_blocks(t.M) * 2 * D);   // x2: micro-batches
   }
   w.max_probs = 2 * (4 * c.depth + 1);
   w.probs = (FcTnProblem*)bp.take(sizeof(FcTnProblem) * w.max_probs);
-  w.max_ln = 4 * c.depth;
+  w.max_ln = 8 * c.depth;
   w.lntab = (FcLnReduce*)bp.take(sizeof(FcLnReduce) * w.max_ln);
   w.loss_scratch = (float*)bp.take(sizeof(float) * (2 * (size_t)B * B + 2 * B + 64));
   w.bytes = bp.off;
   w.B = B; w.n_txt = n_txt;
+  w.dp_stride = B; w.dp_off = 0;
+}
+
+// View of the workspace restricted to samples [b0, b0+bn) of tower i (micro-batch `mb`): every per-row pointer is advanced,
+// so the unchanged forward / backward code runs on the slice.  The image tower is processed as two such slices on two
+// streams: the chains are independent until the loss, and their latency-bound kernels fill each other's gaps.
+static Ws slice_ws(const fc_model* m, const Ws& w, int i, int b0, int bn, int mb) {
+  Ws v = w;
+  const fc_model_cfg& c = m->cfg;
+  const size_t es = fc_esize(m->dt);
+  TowerWs& t = v.t[i];
+  const TowerWs& f = w.t[i];
+  const int N = f.N, D = c.dim, Hd = c.mlp_hidden, H = c.heads;
+  const size_t r0 = (size_t)b0 * N;
+  auto adv = [&](void* p, size_t bytes_per_row) -> void* { return p ? (void*)((char*)p + r0 * bytes_per_row) : nullptr; };
+  t.M = bn * N;
+  if (i == 0) {
+    const size_t kp = (size_t)c.in_chans * c.patch * c.patch;
+    t.patches = f.patches ? (void*)((char*)f.patches + (size_t)b0 * (N - 1) * kp * es) : nullptr;
+    t.dtok = f.dtok ? (void*)((char*)f.dtok + (size_t)b0 * (N - 1) * D * es) : nullptr;
+  } else {
+    t.emb_mean = f.emb_mean + r0;
+    t.emb_rstd = f.emb_rstd + r0;
+  }
+  for (size_t l = 0; l < f.x.size(); ++l) { t.x[l] = adv(f.x[l], D * es); t.gx[l] = adv(f.gx[l], D * es); }
+  for (size_t l = 0; l < f.L.size(); ++l) {
+    const LayerWs& a = f.L[l];
+    LayerWs& b = t.L[l];
+    b.mean1 = a.mean1 + r0; b.rstd1 = a.rstd1 + r0; b.mean2 = a.mean2 + r0; b.rstd2 = a.rstd2 + r0;
+    b.lse = a.lse + (size_t)b0 * H * N;
+    b.h1 = adv(a.h1, D * es); b.o = adv(a.o, D * es); b.xmid = adv(a.xmid, D * es); b.h2 = adv(a.h2, D * es);
+    b.gxmid = adv(a.gxmid, D * es); b.gdm = adv(a.gdm, D * es); b.gda = adv(a.gda, D * es);
+    b.qkv = adv(a.qkv, 3 * D * es); b.gdqkv = adv(a.gdqkv, 3 * D * es);
+    b.u = adv(a.u, Hd * es); b.gact = adv(a.gact, Hd * es); b.gdu = adv(a.gdu, Hd * es);
+  }
+  const int nc = m->tw[i].ncls > 0 ? m->tw[i].ncls : 1;
+  t.f = f.f + (size_t)b0 * D; t.hmean = f.hmean + b0; t.hrstd = f.hrstd + b0; t.nrm = f.nrm + b0; t.out = f.out + (size_t)b0 * D;
+  t.logits = f.logits + (size_t)b0 * nc; t.dlogits = f.dlogits + (size_t)b0 * nc; t.df = f.df + (size_t)b0 * D;
+  t.dh = adv(f.dh, D * es); t.dO = adv(f.dO, D * es);
+  t.delta = f.delta + (size_t)b0 * H * N;
+  t.ln_partial = f.ln_partial + (size_t)mb * 2 * c.depth * fc_layernorm_bwd_partial_blocks(f.M) * 2 * D;
+  v.B = bn;
+  v.dp_off = w.dp_off + b0;
+  return v;
+}
+static int microbatches(const fc_model* m, int B) {
+  static int req = getenv("FC_MICROBATCH") ? atoi(getenv("FC_MICROBATCH")) : 2;
+  return (m->dt == FC_BF16 && req >= 2 && B >= 16) ? 2 : 1;
 }
 
 extern "C" size_t fc_workspace_bytes(const fc_model_t* m, int32_t B, int32_t n_txt) {
@@ -344,6 +399,8 @@ struct Ctx {
   size_t es;
   std::vector<FcTnProblem>* defer = nullptr;   // non-null: weight/bias gradients are queued for the grouped launch
   struct DwState* dw = nullptr;                // chunked early launches of the queued problems
+  bool no_wgrad = false;                       // micro-batch slice: the full-batch weight gradients are queued by the driver
+  hipStream_t s2nd = nullptr;                  // flush_dw also orders the chunk after this stream (second micro-batch)
   std::vector<FcLnReduce>* lnq = nullptr;      // non-null: LayerNorm dgamma/dbeta partials are queued likewise
   int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res, void* dx, float* dg,
              float* db, int M, int D, float* partial) const {
@@ -414,9 +471,9 @@ static int rowscale(int dt, const void* src, void* dst, const float* rs, int row
   return 0;
 }
 
-static const float* dp_ptr(const fc_model* m, const float* droppath, int tower, int layer, int branch, int B) {
-  if (!droppath) return nullptr;
-  return droppath + (((size_t)tower * m->cfg.depth + layer) * 2 + branch) * B;
+static const float* dp_ptr(const fc_model* m, const Ws& w, int tower, int layer, int branch) {
+  if (!w.droppath) return nullptr;
+  return w.droppath + (((size_t)tower * m->cfg.depth + layer) * 2 + branch) * w.dp_stride + w.dp_off;
 }
 
 // ---------------------------------------------------------------- forward (mome.py:881-922)
@@ -447,12 +504,12 @@ static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int
     FC_TRY(fc_layernorm_fwd(c.dt, t.x[l], P + b.n1w, P + b.n1b, L.h1, L.mean1, L.rstd1, M, D, 1e-5f, c.s));
     { GemmEpi e; e.bias = P + b.qkv.b; FC_TRY(c.gemm_fwd(L.h1, c.W(b.qkv.w), L.qkv, M, 3 * D, D, e)); }
     FC_TRY(c.attn_fwd(L.qkv, L.o, L.lse, B, N));
-    { GemmEpi e; e.bias = P + b.proj.b; e.res = t.x[l]; e.rowscale = dp_ptr(m, w.droppath, i, l, 0, B); e.rows_per_sample = N;
+    { GemmEpi e; e.bias = P + b.proj.b; e.res = t.x[l]; e.rowscale = dp_ptr(m, w, i, l, 0); e.rows_per_sample = N;
       FC_TRY(c.gemm_fwd(L.o, c.W(b.proj.w), L.xmid, M, D, D, e)); }
     FC_TRY(fc_layernorm_fwd(c.dt, L.xmid, P + b.n2w, P + b.n2b, L.h2, L.mean2, L.rstd2, M, D, 1e-5f, c.s));
     { GemmEpi e; e.bias = P + b.fc1.b; e.preact = L.u; e.gelu_saved_grad = (c.dt == FC_BF16);   // bf16: L.u holds gelu'(u)
       FC_TRY(c.gemm_fwd(L.h2, c.W(b.fc1.w), L.gact, M, Hd, D, e)); }
-    { GemmEpi e; e.bias = P + b.fc2.b; e.res = L.xmid; e.rowscale = dp_ptr(m, w.droppath, i, l, 1, B); e.rows_per_sample = N;
+    { GemmEpi e; e.bias = P + b.fc2.b; e.res = L.xmid; e.rowscale = dp_ptr(m, w, i, l, 1); e.rows_per_sample = N;
       FC_TRY(c.gemm_fwd(L.gact, c.W(b.fc2.w), t.x[l + 1], M, D, Hd, e)); }
   }
   int normalize = feat_out || tp.task == FC_TASK_RTV;
@@ -473,6 +530,9 @@ static int ensure_side(const fc_model* m) {
   if (!m->dws) {
     FC_CHECK_HIP(hipStreamCreateWithFlags(&m->dws, hipStreamNonBlocking));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in, hipEventDisableTiming));
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in2, hipEventDisableTiming));
+    FC_CHECK_HIP(hipStreamCreateWithFlags(&m->mbs, hipStreamNonBlocking));
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_mb_join, hipEventDisableTiming));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_out, hipEventDisableTiming));
   }
   if (!m->side) {
@@ -482,15 +542,18 @@ static int ensure_side(const fc_model* m) {
   }
   return 0;
 }
-static int fork_side(const fc_model* m, hipStream_t s) {
+static int fork_side(const fc_model* m, hipStream_t s) {   // side (text tower) and micro-batch streams start after `s`
   FC_TRY(ensure_side(m));
   FC_CHECK_HIP(hipEventRecord(m->ev_fork, s));
   FC_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+  FC_CHECK_HIP(hipStreamWaitEvent(m->mbs, m->ev_fork, 0));
   return 0;
 }
 static int join_side(const fc_model* m, hipStream_t s) {
   FC_CHECK_HIP(hipEventRecord(m->ev_join, m->side));
   FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
+  FC_CHECK_HIP(hipEventRecord(m->ev_mb_join, m->mbs));
+  FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_mb_join, 0));
   return 0;
 }
 
@@ -513,12 +576,23 @@ static int forward_impl(const fc_model* m, const float* params, const void* wc, 
   w.feat_out = feat_out; w.droppath = droppath; w.ids = ids;
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
   const bool both = m->tw[0].present && m->tw[1].present;
-  if (both) {   // text tower on the side stream, concurrently with the image tower
+  if (both) {   // text tower on the side stream, image tower as two micro-batch chains on two more streams
     FC_TRY(fork_side(m, s));
     Ctx c2 = c;
     c2.s = m->side;
-    FC_TRY(tower_forward(c, w, 0, img, nullptr, feat_out, out_img));
     FC_TRY(tower_forward(c2, w, 1, nullptr, ids, feat_out, out_txt));
+    if (microbatches(m, B) == 2) {
+      const int b1 = B / 2;
+      const size_t ipx = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
+      const size_t ow = (size_t)((feat_out || m->tw[0].task == FC_TASK_RTV) ? m->cfg.dim : m->tw[0].ncls);
+      Ws wa = slice_ws(m, w, 0, 0, b1, 0), wb = slice_ws(m, w, 0, b1, B - b1, 1);
+      Ctx cb = c;
+      cb.s = m->mbs;
+      FC_TRY(tower_forward(c, wa, 0, img, nullptr, feat_out, out_img));
+      FC_TRY(tower_forward(cb, wb, 0, img + (size_t)b1 * ipx, nullptr, feat_out, out_img ? out_img + (size_t)b1 * ow : nullptr));
+    } else {
+      FC_TRY(tower_forward(c, w, 0, img, nullptr, feat_out, out_img));
+    }
     FC_TRY(join_side(m, s));
     return 0;
   }
@@ -576,12 +650,17 @@ static int flush_dw(const Ctx& c) {
   }
   FC_CHECK_HIP(hipEventRecord(m->ev_dw_in, c.s));
   FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in, 0));
+  if (c.s2nd) {
+    FC_CHECK_HIP(hipEventRecord(m->ev_dw_in2, c.s2nd));
+    FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in2, 0));
+  }
   FC_TRY(fc_gemm_tn_grouped(st.dev + beg, (int)n, tiles, m->dws));
   st.flushed = all.size();
   return 0;
 }
 
 static int weight_grad(const Ctx& c, const void* dY, const void* X, int M, int out, int in, float* dW, float* db) {
+  if (c.no_wgrad) return 0;
   if (c.defer) {
     FcTnProblem p{(const bf16_t*)dY, (const bf16_t*)X, dW, db, out, in, in, out, in, M, 0, 0};
     if (fc_gemm_tn_grouped_supported(p)) { c.defer->push_back(p); return 0; }
@@ -594,7 +673,10 @@ static int linear_bwd_params(const Ctx& c, const LinearP& L, const void* dY, con
   return weight_grad(c, dY, X, M, L.out, L.in, grads + L.w, grads + L.b);
 }
 
-static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float* grads) {
+enum { PH_ALL = -1, PH_HEAD = 0, PH_LAYER = 1, PH_EMBED = 2, PH_WGRAD_LAYER = 3, PH_WGRAD_EMBED = 4 };
+// phase PH_ALL runs the whole tower; the micro-batched driver calls it phase by phase (PH_LAYER: layer `lsel` only).
+// PH_WGRAD_*: only queue the weight-gradient problems of layer `lsel` / of the patch embedding (full-batch view).
+static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float* grads, int phase = PH_ALL, int lsel = -1) {
   const fc_model* m = c.m;
   const fc_model_cfg& cf = m->cfg;
   const TowerP& tp = m->tw[i];
@@ -603,6 +685,8 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
   const float* P = c.params;
   int normalize = w.feat_out || tp.task == FC_TASK_RTV;
   const float* din = d_out;
+  const bool wg_only = (phase == PH_WGRAD_LAYER || phase == PH_WGRAD_EMBED);
+  if (phase == PH_ALL || phase == PH_HEAD) {
   if (!normalize) {  // ClassificationHead backward (mome.py:647-649)
     GemmEpi e;
     FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, d_out, tp.ncls, 1, P + tp.head_w, D, 1, t.df, D, B, D, tp.ncls, e, c.s));      // df = dlogits . Wh
@@ -613,12 +697,23 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
   }
   FC_TRY(fc_head_bwd(c.dt, din, t.out, t.nrm, normalize, t.x[cf.depth], t.hmean, t.hrstd, P + m->normw, t.gx[cf.depth], grads + m->normw,
                      grads + m->normb, B, N, D, c.s));
+  }
   for (int l = cf.depth - 1; l >= 0; --l) {
+    if (!(phase == PH_ALL || ((phase == PH_LAYER || phase == PH_WGRAD_LAYER) && l == lsel))) continue;
     const BlockP& b = tp.blocks[l];
     LayerWs& L = t.L[l];
     const void* dx = t.gx[l + 1];
+    if (wg_only) {   // same operand choice as below, no kernels: queue dW / db of this layer over the full batch
+      const void* dm = dp_ptr(m, w, i, l, 1) ? (const void*)L.gdm : dx;
+      const void* da = dp_ptr(m, w, i, l, 0) ? (const void*)L.gda : (const void*)L.gxmid;
+      FC_TRY(linear_bwd_params(c, b.fc2, dm, L.gact, M, grads));
+      FC_TRY(linear_bwd_params(c, b.fc1, L.gdu, L.h2, M, grads));
+      FC_TRY(linear_bwd_params(c, b.proj, da, L.o, M, grads));
+      FC_TRY(linear_bwd_params(c, b.qkv, L.gdqkv, L.h1, M, grads));
+      continue;
+    }
     // ---- MLP branch: x_{l+1} = xmid + s2 * (gact.W2^T + b2)
-    const float* s2 = dp_ptr(m, w.droppath, i, l, 1, B);
+    const float* s2 = dp_ptr(m, w, i, l, 1);
     const void* dm = dx;
     if (s2) { FC_TRY(rowscale(c.dt, dx, L.gdm, s2, N, M, D, c.s)); dm = L.gdm; }
     FC_TRY(linear_bwd_params(c, b.fc2, dm, L.gact, M, grads));
@@ -628,7 +723,7 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
     { GemmEpi e; FC_TRY(c.gemm_dx(L.gdu, c.W(b.fc1.w), t.dh, M, Hd, D, e)); }                                  // dh2
     FC_TRY(c.ln_bwd(t.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, dx, L.gxmid, grads + b.n2w, grads + b.n2b, M, D, t.ln_partial + (2 * l + 1) * lnp));
     // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp)
-    const float* s1 = dp_ptr(m, w.droppath, i, l, 0, B);
+    const float* s1 = dp_ptr(m, w, i, l, 0);
     const void* da = L.gxmid;
     if (s1) { FC_TRY(rowscale(c.dt, L.gxmid, L.gda, s1, N, M, D, c.s)); da = L.gda; }
     FC_TRY(linear_bwd_params(c, b.proj, da, L.o, M, grads));
@@ -637,8 +732,13 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
     FC_TRY(linear_bwd_params(c, b.qkv, L.gdqkv, L.h1, M, grads));
     { GemmEpi e; FC_TRY(c.gemm_dx(L.gdqkv, c.W(b.qkv.w), t.dh, M, 3 * D, D, e)); }                             // dh1
     FC_TRY(c.ln_bwd(t.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, L.gxmid, t.gx[l], grads + b.n1w, grads + b.n1b, M, D, t.ln_partial + (2 * l) * lnp));
-    if (l % dw_flush_every() == 0 && l > 0) FC_TRY(flush_dw(c));   // this chunk's weight gradients start now, under the remaining layers
+    if (phase == PH_ALL && l % dw_flush_every() == 0 && l > 0) FC_TRY(flush_dw(c));   // this chunk's weight gradients start now
   }
+  if (phase == PH_WGRAD_EMBED) {
+    if (i == 0) FC_TRY(weight_grad(c, t.dtok, t.patches, B * (N - 1), D, cf.in_chans * cf.patch * cf.patch, grads + tp.pw, grads + tp.pb));
+    return 0;
+  }
+  if (!(phase == PH_ALL || phase == PH_EMBED)) return 0;
   const void* dx = t.gx[0];
   if (i == 0) {
     int np = N - 1, kp = cf.in_chans * cf.patch * cf.patch;
@@ -648,7 +748,7 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
     FC_TRY(fc_txt_embed_bwd(c.dt, dx, w.ids, P + tp.word, P + tp.tpos, P + tp.ttype, t.emb_mean, t.emb_rstd, P + tp.lnw, grads + tp.word,
                             grads + tp.tpos, grads + tp.ttype, grads + tp.lnw, grads + tp.lnb, B, N, D, cf.vocab, c.s));
   }
-  FC_TRY(flush_dw(c));
+  if (phase == PH_ALL) FC_TRY(flush_dw(c));
   return 0;
 }
 
@@ -688,8 +788,33 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     FC_TRY(fork_side(m, s));
     Ctx c2 = c;
     c2.s = m->side;
-    FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
-    FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads));
+    FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads));      // text tower (short) first: its dW chunks start early
+    if (microbatches(m, w.B) == 2 && c.defer) {
+      // image tower as two micro-batch chains, interleaved layer by layer; the full-batch weight gradients of a layer are
+      // queued once both chains have enqueued it, and flushed to the dW stream every few layers behind BOTH chains
+      const int b1 = w.B / 2;
+      const size_t ow = (size_t)((w.feat_out || m->tw[0].task == FC_TASK_RTV) ? m->cfg.dim : m->tw[0].ncls);
+      Ws wa = slice_ws(m, w, 0, 0, b1, 0), wb = slice_ws(m, w, 0, b1, w.B - b1, 1);
+      Ctx ca = c, cb = c, cf_ = c;
+      ca.no_wgrad = cb.no_wgrad = true;
+      cb.s = m->mbs;
+      cf_.lnq = nullptr;          // (no kernels run through the full-batch context)
+      cf_.s2nd = m->mbs;
+      FC_TRY(tower_backward(ca, wa, 0, d_out_img, grads, PH_HEAD));
+      FC_TRY(tower_backward(cb, wb, 0, d_out_img + (size_t)b1 * ow, grads, PH_HEAD));
+      for (int l = m->cfg.depth - 1; l >= 0; --l) {
+        FC_TRY(tower_backward(ca, wa, 0, d_out_img, grads, PH_LAYER, l));
+        FC_TRY(tower_backward(cb, wb, 0, d_out_img, grads, PH_LAYER, l));
+        FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_LAYER, l));
+        if (l % dw_flush_every() == 0 && l > 0) FC_TRY(flush_dw(cf_));
+      }
+      FC_TRY(tower_backward(ca, wa, 0, d_out_img, grads, PH_EMBED));
+      FC_TRY(tower_backward(cb, wb, 0, d_out_img, grads, PH_EMBED));
+      FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_EMBED));
+      FC_TRY(flush_dw(cf_));
+    } else {
+      FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
+    }
     FC_TRY(join_side(m, s));
   } else {
     if (run0) FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
