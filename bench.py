@@ -207,6 +207,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    t_enq = time.perf_counter() - t0        # host time to enqueue the steps (launch-bound if close to dt)
     aggregate()
     barrier()
     dt = time.perf_counter() - t0
@@ -223,7 +224,7 @@ def main():
                    config=dict(workload="Flickr30k FedCola, 1 img-txt client per GPU, mome_small_patch16 (ViT-S + 12x384 text tower), "
                                         f"B={B}, 224x224 RGB, {seq}-token captions, vocab 7732, AdamW lr 1e-4, drop-path 0",
                                global_batch=world * B, parallelism=f"{world} concurrent clients + RCCL FedAvg all-reduce"),
-                   step_mfma_frac=round(pairs * PAIR_GFLOP / 1e3 / (world * PEAK_BF16_TFLOPS), 4), last_loss=round(loss, 4))
+                   step_mfma_frac=round(pairs * PAIR_GFLOP / 1e3 / (world * PEAK_BF16_TFLOPS), 4), last_loss=round(loss, 4), enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
         if not a.no_roofline:
             out["roofline"] = gemm_roofline()
         if cpu_base is not None:

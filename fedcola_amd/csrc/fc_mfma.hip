@@ -405,10 +405,39 @@ __device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, size_t elem
 }
 // store instructions one thread issues per output tile with the compile-time epilogues (0: unknown -> full drain)
 template <int EPI, typename TC> struct EpiStores { static constexpr int n = EPI == EPI_GENERIC ? 0 : ((EPI == EPI_GELU || EPI == EPI_GELU_SG) ? 16 : 8) * (sizeof(TC) == 2 ? 1 : 2); };
-// one half (64 rows starting at tile row `rbase`) of the fused epilogue; thread owns columns 8*(tid&15).. and rows (tid>>4) + 16q
+// Global inputs of a tile's epilogue (bias, residual / GELU' operand, drop-path scale), requested for BOTH halves before the
+// tile's last k-step: vmcnt retires in order, so a load issued after a store cannot be waited for without also waiting
+// out that store's write latency -- loading inside each half serialised every half behind the previous half's stores.
+struct EpiRegs { float bias[8]; uint4 rin0[4], rin1[4]; float sc0[4], sc1[4]; };   // always a local of the kernel: lives in VGPRs
+template <int EPI, typename TC> struct EpiPre {
+  static constexpr bool on = sizeof(TC) == 2 && EPI != EPI_GENERIC && EPI != EPI_PATCH;
+};
+#define TILE_ROW2(row, hp) ((((row) >> 5) << 6) + (hp) * 32 + ((row) & 31))
 template <int EPI, typename TC>
+__device__ __forceinline__ void epi_prefetch(EpiRegs& R, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid) {
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_GELU_SG;
+  constexpr bool HAS_RES = EPI == EPI_RES || EPI == EPI_RES_SCALE;
+  constexpr bool HAS_IN = EPI == EPI_GELU_GRAD || EPI == EPI_MUL;
+  const int c8 = (tid & 15) * 8, n = n0 + c8, r0 = tid >> 4;
+  const int nc = n < N ? n : N - 8;
+  if (HAS_BIAS) Vec8<float>::ld(e.bias + nc, R.bias);
+  if (HAS_RES || HAS_IN || EPI == EPI_RES_SCALE) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ma = m0 + TILE_ROW2(r0 + 16 * q, 0), mb = m0 + TILE_ROW2(r0 + 16 * q, 1);
+      const int mca = ma < M ? ma : M - 1, mcb = mb < M ? mb : M - 1;
+      const size_t offa = (size_t)mca * ldc + nc, offb = (size_t)mcb * ldc + nc;
+      if (HAS_RES) { R.rin0[q] = *(const uint4*)((const bf16_t*)e.res + offa); R.rin1[q] = *(const uint4*)((const bf16_t*)e.res + offb); }
+      if (HAS_IN) { R.rin0[q] = *(const uint4*)((const bf16_t*)e.gelu_in + offa); R.rin1[q] = *(const uint4*)((const bf16_t*)e.gelu_in + offb); }
+      if (EPI == EPI_RES_SCALE) { R.sc0[q] = e.rowscale[mca / e.rows_per_sample]; R.sc1[q] = e.rowscale[mcb / e.rows_per_sample]; }
+    }
+  }
+}
+// one half (64 rows starting at tile row `rbase`) of the fused epilogue; thread owns columns 8*(tid&15).. and rows (tid>>4) + 16q
+template <int EPI, typename TC, bool PRE = false>
 __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid, int hp,
-                                              __amdgpu_buffer_rsrc_t crs, __amdgpu_buffer_rsrc_t prs) {
+                                              __amdgpu_buffer_rsrc_t crs, __amdgpu_buffer_rsrc_t prs, const float (&pbias)[8],
+                                              const uint4 (&prin)[4], const float (&psc)[4]) {
   const int c8 = (tid & 15) * 8, n = n0 + c8, r0 = tid >> 4;
 #define TILE_ROW(row) ((((row) >> 5) << 6) + hp * 32 + ((row) & 31))   /* image row -> row inside the 128-row tile */
   if (EPI == EPI_GENERIC) {
@@ -428,8 +457,16 @@ __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, 
   constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_GELU_SG || EPI == EPI_PATCH;
   constexpr bool HAS_RES = EPI == EPI_RES || EPI == EPI_RES_SCALE;
   const int nc = n < N ? n : N - 8;
+  constexpr bool use_pre = EpiPre<EPI, TC>::on && PRE;
   float bias[8];
-  if (HAS_BIAS) Vec8<float>::ld(e.bias + nc, bias);
+  if (HAS_BIAS) {
+    if (use_pre) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias[i] = pbias[i];
+    } else {
+      Vec8<float>::ld(e.bias + nc, bias);
+    }
+  }
   float rin[4][8], rpos[4][8], sc[4];
   size_t off[4];
 #pragma unroll
@@ -439,6 +476,17 @@ __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, 
     long orow = mc;
     if (EPI == EPI_PATCH) orow = (long)mc + mc / e.patch_rows + 1;
     off[q] = (size_t)orow * ldc + nc;
+    if (use_pre) {
+      if (HAS_RES || EPI == EPI_GELU_GRAD || EPI == EPI_MUL) {
+        const uint4 u = prin[q];
+        rin[q][0] = __uint_as_float(u.x << 16); rin[q][1] = __uint_as_float(u.x & 0xffff0000u);
+        rin[q][2] = __uint_as_float(u.y << 16); rin[q][3] = __uint_as_float(u.y & 0xffff0000u);
+        rin[q][4] = __uint_as_float(u.z << 16); rin[q][5] = __uint_as_float(u.z & 0xffff0000u);
+        rin[q][6] = __uint_as_float(u.w << 16); rin[q][7] = __uint_as_float(u.w & 0xffff0000u);
+      }
+      if (EPI == EPI_RES_SCALE) sc[q] = psc[q];
+      continue;
+    }
     if (HAS_RES) Vec8<TC>::ld((const TC*)e.res + off[q], rin[q]);
     if (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) Vec8<TC>::ld((const TC*)e.gelu_in + off[q], rin[q]);
     if (EPI == EPI_PATCH) Vec8<float>::ld(e.pos + (size_t)(1 + mc % e.patch_rows) * N + nc, rpos[q]);
@@ -497,6 +545,14 @@ __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, 
     buf_store8<TC>(crs, off[q], ok, v);
   }
 #undef TILE_ROW
+}
+template <int EPI, typename TC>
+__device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid, int hp,
+                                              __amdgpu_buffer_rsrc_t crs, __amdgpu_buffer_rsrc_t prs) {
+  const float b[8] = {};
+  const uint4 r[4] = {};
+  const float c[4] = {};
+  half_epilogue<EPI, TC, false>(Cs, C, ldc, m0, n0, M, N, e, tid, hp, crs, prs, b, r, c);
 }
 
 // ---- main loop shared by the single-problem and the grouped kernels.
@@ -618,7 +674,9 @@ k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B
   const __amdgpu_buffer_rsrc_t crs = make_store_rsrc((void*)C, crows * ldc * (long)sizeof(TC));
   const __amdgpu_buffer_rsrc_t prs = make_store_rsrc(e.preact ? e.preact : (void*)C, crows * ldc * (long)sizeof(TC));
   constexpr int NST = EpiStores<EPI, TC>::n;
+  EpiRegs pre;
   for (int ct = first; ct < ntiles; ct += G) {
+    const int m0 = (ct / tiles_n) * BM, n0 = (ct % tiles_n) * BN;
     for (int k = 0; k < T; ++k) {
       // this wave's pieces of the current k-tile have landed.  Right after an epilogue the youngest NST operations are that
       // epilogue's stores (a fixed count per thread): skip them instead of draining the HBM write latency.
@@ -627,21 +685,21 @@ k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B
       __builtin_amdgcn_s_barrier();                        // ... everyone's have, and the other buffer is no longer being read
       asm volatile("" ::: "memory");
       ISSUE_NEXT();                                        // next k-tile (possibly of the next output tile) -> other buffer
+      if (EpiPre<EPI, TC>::on && k == T - 1) epi_prefetch<EPI, TC>(pre, ldc, m0, n0, M, N, e, tid);   // lands under the last MFMAs
       tile_compute<AMODE, BMODE>(smem + cb * 32768, acc, wm, wn, lane);
       cb ^= 1;
     }
     // ---- epilogue, two 64-row halves through the staging buffer that was computed last (the other one is receiving the
     // next tile's first k-tile by DMA meanwhile)
     float* Cs = (float*)(smem + (cb ^ 1) * 32768);
-    const int m0 = (ct / tiles_n) * BM, n0 = (ct % tiles_n) * BN;
     lds_barrier();                                         // last MFMA fragment reads of this buffer are done
     acc_to_lds_half<0>(Cs, acc, wm, wn, lane);
     lds_barrier();
-    half_epilogue<EPI, TC>(Cs, C, ldc, m0, n0, M, N, e, tid, 0, crs, prs);
+    half_epilogue<EPI, TC, true>(Cs, C, ldc, m0, n0, M, N, e, tid, 0, crs, prs, pre.bias, pre.rin0, pre.sc0);
     lds_barrier();
     acc_to_lds_half<1>(Cs, acc, wm, wn, lane);
     lds_barrier();
-    half_epilogue<EPI, TC>(Cs, C, ldc, m0, n0, M, N, e, tid, 1, crs, prs);
+    half_epilogue<EPI, TC, true>(Cs, C, ldc, m0, n0, M, N, e, tid, 1, crs, prs, pre.bias, pre.rin1, pre.sc1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -651,6 +709,7 @@ k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef ISSUE_NEXT
 }
+
 
 // ======================================================================== grouped weight-gradient GEMM
 // All dW = dY^T . X products of a backward pass (every linear of every layer of both towers) in ONE launch, each output

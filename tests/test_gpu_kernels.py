@@ -77,7 +77,8 @@ def test_layernorm(prec, M, D):
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("kind", [0, 1, 2])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("M,N,K", [(5, 7, 3), (70, 130, 33), (197 * 4, 384, 384), (256, 1152, 384), (394, 384, 1536), (1000, 192, 768)])
+@pytest.mark.parametrize("M,N,K", [(5, 7, 3), (70, 130, 33), (197 * 4, 384, 384), (256, 1152, 384), (394, 384, 1536), (1000, 192, 768),
+                                   (197 * 22, 1152, 384), (4100, 1048, 200)])   # several persistent rounds per workgroup
 def test_gemm(impl, kind, prec, M, N, K):
     if impl == 1 and prec == "fp32":
         pytest.skip("MFMA path is bf16")

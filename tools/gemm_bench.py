@@ -10,6 +10,9 @@ only = sys.argv[2] if len(sys.argv) > 2 else None
 shapes = [("NT fc1", 0, 12608, 1536, 384), ("NT qkv", 0, 12608, 1152, 384), ("NT proj", 0, 12608, 384, 384), ("NT fc2", 0, 12608, 384, 1536),
           ("NN dfc2", 1, 12608, 1536, 384), ("NN dfc1", 1, 12608, 384, 1536), ("NN dqkv", 1, 12608, 384, 1152), ("TN dWfc1", 2, 1536, 384, 12608),
           ("NT txt fc1", 0, 2048, 1536, 384), ("NT txt proj", 0, 2048, 384, 384)]
+if os.environ.get("GEMM_SHAPES"):   # "kind,M,N,K;kind,M,N,K"
+    shapes = [("custom", *map(int, t.split(","))) for t in os.environ["GEMM_SHAPES"].split(";")]
+    only = None
 sp = _lib.stream_ptr()
 for name, kind, M, N, K in shapes:
     if only and only not in name: continue
