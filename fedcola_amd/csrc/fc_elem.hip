@@ -173,7 +173,9 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
 #undef RED
 }
 
-// grouped reduction of the LayerNorm-backward partials: block (x = column chunk of 64, y = LN instance)
+// grouped reduction of the LayerNorm-backward partials: block (x = column chunk of 64, y = LN instance, z = slice of the
+// partial rows); the slices meet in the final atomic add (the gradient buffer is zeroed at the start of the step)
+#define LNR_SLICES 8
 __global__ void __launch_bounds__(256) k_ln_reduce_grouped(const FcLnReduce* __restrict__ tab) {
   __shared__ float red[4][64];
   const FcLnReduce e = tab[blockIdx.y];
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(256) k_ln_reduce_grouped(const FcLnReduce* __r
   int W = 2 * e.D;
   float acc = 0.f;
   if (col < W)
-    for (int bk = wave; bk < e.nblocks; bk += 4) acc += e.partial[(size_t)bk * W + col];
+    for (int bk = blockIdx.z * 4 + wave; bk < e.nblocks; bk += 4 * LNR_SLICES) acc += e.partial[(size_t)bk * W + col];
   red[wave][threadIdx.x & 63] = acc;
   __syncthreads();
   if (wave == 0 && col < W) {
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(256) k_ln_reduce_grouped(const FcLnReduce* __r
 }
 int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_ln_reduce_grouped, dim3(fc_cdiv(2 * maxD, 64), n), dim3(256), 0, s, tab_dev);
+  hipLaunchKernelGGL(k_ln_reduce_grouped, dim3(fc_cdiv(2 * maxD, 64), n, LNR_SLICES), dim3(256), 0, s, tab_dev);
   FC_LAUNCH_CHECK();
   return 0;
 }
