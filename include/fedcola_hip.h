@@ -116,6 +116,17 @@ int fc_scale_segments(float* buf, const int64_t* seg_offset, const int64_t* seg_
 /* FedavgClient.upload aux fold (fedavgclient.py:173-181): dst[weight] = W + A*s for every re-param linear, rest copied */
 int fc_upload_fold(const fc_model_t* m, const float* params, float* dst, void* stream);
 
+/* ---- retrieval evaluation: COCOEvaluator.evaluate_recall (src/metrics/eval_coco.py:296-351,
+ * ParallelMatMulModule :48-69) on device.  q [nq,d], g [ng,d]: float64 row-major features (the reference holds the extracted
+ * features as float64, eval_coco.py:155-156, and multiplies them with Tensor.mm, :55); labels: int64 class ids
+ * (image ids / class ids, eval_coco.py:166-173).  best_ranks[i] = position, in the descending-similarity order of the
+ * gallery (equal similarities: lower gallery index first), of the best-placed gallery item whose label equals
+ * q_labels[i] (eval_coco.py:331-334); -1 when no gallery item has that label (the reference raises there).
+ * scratch: fp64 similarity rows of one query batch; fc_retrieval_scratch_bytes(nq_batch, ng) sizes it (any nq_batch >= 1). */
+size_t fc_retrieval_scratch_bytes(int32_t nq_batch, int32_t ng);
+int fc_retrieval_best_ranks(const double* q, const double* g, const int64_t* q_labels, const int64_t* g_labels, int32_t nq,
+                            int32_t ng, int32_t d, void* scratch, size_t scratch_bytes, int64_t* best_ranks, void* stream);
+
 /* ---- individual kernels exposed for unit tests / reuse (dt: 0 = f32, 1 = bf16) */
 int fc_k_layernorm_fwd(int32_t dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
                        int32_t M, int32_t D, float eps, void* stream);
@@ -133,6 +144,8 @@ int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, const void* o,
 int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
                int32_t step, void* stream);
 int fc_k_cast(int32_t dt_out, const float* src, void* dst, int64_t n, void* stream);
+/* sims[nq,ng] = q . g^T in float64 (v_mfma_f64_16x16x4_f64) */
+int fc_k_sim_f64(const double* q, const double* g, double* sims, int32_t nq, int32_t ng, int32_t d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@ Outputs (tests/golden/):
     agg.json            FedavgServer._aggregate outputs over the scope / compensation matrix
     sampling.json       FedavgServer._sample_clients id lists
     init.json           default-init state_dict fingerprints under torch.manual_seed (factory order check)
+    retrieval.json      COCOEvaluator.extract_features ordering, best ranks and recall scores on synthetic features
 
 Inputs and weights are NOT stored: they come from tests/synth.py's exact integer generator, so a fixture
 is only (generator seeds, expected outputs).
@@ -265,10 +266,51 @@ def init_case():
     print("init ok")
 
 
+def retrieval_case():
+    """COCOEvaluator (src/metrics/eval_coco.py) on synthetic features: collected ordering, best ranks, scores."""
+    import importlib
+    import numpy as np
+    from retrieval_util import RETRIEVAL_CASES, FakeDataset, FakeLoader, PassThroughModel, retrieval_set, stream
+    ec = importlib.import_module("src.metrics.eval_coco")
+    recs = {}
+    for name, c in RETRIEVAL_CASES.items():
+        img, cap, iids, aids = retrieval_set(c["n_images"], c["caps"], c["D"], c["seed"])
+        batches = stream(img, cap, iids, aids, c["caps"], c["batch"])
+        ev = ec.COCOEvaluator("matmul", n_crossfolds=c["folds"], extract_device="cpu", eval_device="cpu", verbose=False)
+        ev.set_model(PassThroughModel(c["D"]))
+        loader = FakeLoader(batches, FakeDataset(c["n_images"], cap.shape[0]))
+        ex = ev.extract_features(loader)
+        captured = []
+        orig = ec.recall_at_k
+
+        def spy(ranks, k):
+            if k == 1:
+                captured.append([int(r) for r in ranks])
+            return orig(ranks, k)
+        ec.recall_at_k = spy
+        try:
+            scores = ev.evaluate(loader, n_images_per_crossfold=c["ipf"], n_captions_per_crossfold=c["cpf"], eval_batch_size=64)
+        finally:
+            ec.recall_at_k = orig
+        # evaluate() order: per fold (i2t, t2i), then full i2t, full t2i
+        recs[name] = dict(cfg=c, image_ids=[int(v) for v in ex["image_ids"]], caption_ids=[int(v) for v in ex["caption_ids"]],
+                          caption_classes=[int(v) for v in ex["caption_classes"]],
+                          image_feature_sum=float(ex["image_features"].sum()), caption_feature_sum=float(ex["caption_features"].sum()),
+                          ranks_i2t=captured[-2], ranks_t2i=captured[-1], fold_ranks=captured[:-2],
+                          scores=json.loads(json.dumps(scores, default=float)))
+    with open(os.path.join(HERE, "retrieval.json"), "w") as f:
+        json.dump(recs, f)
+    print("retrieval ok")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "retrieval":
+        retrieval_case()
+        sys.exit(0)
     for n, c in CASES.items():
         model_case(n, c)
     update_case()
     agg_case()
     sampling_case()
     init_case()
+    retrieval_case()
