@@ -6,7 +6,8 @@ the aux-weight refresh, LR decay, and ``finalize``'s checkpoint.
 Scaling model: one process per GPU (``torch.distributed`` over RCCL).  Every rank holds all global models and the full client
 list (bookkeeping is replicated and deterministic); the sampled clients are dealt to ranks by their position in the sorted
 sample, exactly like the reference deals them to ``cuda:(i % n_gpu)`` (fedavgserver.py:310-311).  Out of scope here (the
-reference's control plane / evaluation): wandb logging, COCOEvaluator (``_central_evaluate`` takes an injected evaluator).
+reference's control plane): wandb logging.  Central evaluation follows fedavgserver.py:676-760 with the retrieval evaluator of
+``fedcola_amd.metrics.eval_coco`` (HIP ranking).
 """
 from __future__ import annotations
 
@@ -33,6 +34,7 @@ DATASET_2_MODALITY = {"BraTS": "t1", "MedMNIST": "img", "CIFAR100": "img", "AG_N
 NUM_CLASS = {"CIFAR100": 100, "AG_NEWS": 4, "MedMNIST": 11, "MTSamples": 40, "MedicalAbstracts": 5, "Flickr30k": None, "Coco": None}
 TASK_2_CRITERION = {"cls": "CrossEntropyLoss", "seg": "SegLoss", "img+txt": "ContrastiveLoss"}
 VOCAB_SIZES = {"Flickr30k": 7732, "MedicalAbstracts": 20264}
+MM_METRICS = ("recall_1", "recall_5", "recall_10", "rsum")
 
 get_name_type = agg.get_name_type
 get_name_modality = agg.get_name_modality
@@ -54,7 +56,7 @@ class FedavgServer(BaseServer):
         self.server_dataset = server_dataset[1] if (args.eval_type != "local" and server_dataset is not None) else None
         self.global_models = self._init_model(model_str)
         self._init_param_scope(args.shared_param, args.share_scope)
-        self.evaluator = None
+        self._set_evaluator()
         self.opt_kwargs = dict(lr=self.args.lr, momentum=getattr(self.args, "beta1", 0.0))
         self.curr_lr = self.args.lr
         self.clients = self._create_clients(client_datasets)
@@ -223,14 +225,77 @@ class FedavgServer(BaseServer):
             client.model = None
         gc.collect()
 
+    def _set_evaluator(self):
+        """fedavgserver.py:177-181"""
+        from ..metrics.eval_coco import COCOEvaluator
+        evaluator = COCOEvaluator("matmul", n_crossfolds=5, extract_device=self.args.server_device, eval_device=self.args.server_device,
+                                  verbose=False)
+        evaluator.set_logger(logger)
+        self.evaluator = evaluator
+
+    def _eval_loader(self, dataset, batch_size, shuffle):
+        # the reference spawns 4 persistent loader workers (fedavgserver.py:687,725); loader plumbing is the caller's
+        return torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=shuffle,
+                                           num_workers=getattr(self.args, "eval_num_workers", 0))
+
+    @torch.no_grad()
     def _central_evaluate(self, fedavg=False):
-        """The retrieval evaluator (COCOEvaluator) is outside this build's hot path; an injected ``self.evaluator`` is used if set."""
-        if self.evaluator is None:
-            return None
+        """fedavgserver.py:676-760: img+txt datasets through the retrieval evaluator (1k 5-fold + full-gallery recall), uni-modal
+        datasets through a forward / criterion / MetricManager loop on the server device."""
+        from ..criterions import CRITERIA
+        from ..utils import MetricManager
         out = {}
-        for dataset, model in self.global_models.items():
-            out[dataset] = self.evaluator(model, self.server_dataset[dataset] if self.server_dataset else None)
-        self.results[self.round]["server_evaluated"] = out
+        for dataset in self.server_dataset.keys():
+            tag = f"[{self.args.algorithm.upper()}] [{dataset.upper()}] [Round: {str(self.round).zfill(4)}] [EVALUATE] [SERVER] "
+            if DATASET_2_MODALITY[dataset] == "img+txt":
+                self.global_model = self.global_models[dataset]
+                self.evaluator.set_model(self.global_model)
+                kw = {k: getattr(self.args, k) for k in ("n_images_per_crossfold", "n_captions_per_crossfold") if hasattr(self.args, k)}
+                result = self.evaluator.evaluate(self._eval_loader(self.server_dataset[dataset], self.args.eval_batch_size, True),
+                                                 eval_batch_size=self.args.eval_batch_size, **kw)
+                res_dict = {}
+                for fold, src in (("1k", result.get("n_fold")), ("5k", result)):
+                    if src is None:
+                        continue
+                    for task in ("i2t", "t2i"):
+                        for metric in MM_METRICS:
+                            tag += f"| {dataset}{fold}_{task}_{metric}: {src[task][metric]:.4f} "
+                            res_dict[f"Result/Server {dataset} {fold}_{task}_{metric.title()}"] = src[task][metric]
+                    r1 = src["t2i"]["recall_1"] + src["i2t"]["recall_1"]
+                    tag += f"| {dataset} {fold}_rsum: {r1:.4f} "
+                    res_dict[f"Test/Server {dataset} {fold}_r@1sum"] = r1
+                if result.get("n_fold") is not None:
+                    res_dict[f"Test/Server {dataset} r@1sum"] = (res_dict[f"Test/Server {dataset} 1k_r@1sum"]
+                                                                 + res_dict[f"Test/Server {dataset} 5k_r@1sum"])
+                logger.info(tag)
+                if self.writer is not None:
+                    self.writer.log(res_dict, self.round)
+                out[dataset] = result
+            else:
+                self.global_model = self.global_models[dataset]
+                mm = MetricManager(self.args.eval_metrics)
+                self.global_model.eval()
+                self.global_model.to(self.args.server_device)
+                n = 0
+                for inputs, targets in self._eval_loader(self.server_dataset[dataset], self.args.B, False):
+                    inputs, targets = inputs.to(self.args.server_device), targets.to(self.args.server_device)
+                    if DATASET_2_MODALITY[dataset] == "img":
+                        outputs = self.global_model([inputs, None])[0]
+                    else:
+                        outputs = self.global_model([None, inputs])[1]
+                    loss = CRITERIA[self.args.criterion]()(outputs, targets)
+                    mm.track(loss.item(), outputs, targets)
+                mm.aggregate(len(self.server_dataset[dataset]))
+                result = mm.results
+                tag += f"| loss: {result['loss']:.4f} " + "".join(f"| {k}: {v:.4f} " for k, v in result["metrics"].items())
+                logger.info(tag)
+                suffix = dataset + ("after" if not fedavg else "")
+                if self.writer is not None:
+                    self.writer.log({f"Loss/Server {suffix} Loss": result["loss"]}, self.round)
+                    for name, value in result["metrics"].items():
+                        self.writer.log({f"Test/Server {suffix} {name.title()}": value}, self.round)
+                self.results[self.round][f"server_evaluated_{suffix}"] = result
+                out[dataset] = result
         return out
 
     # ------------------------------------------------------------------ one federated round (fedavgserver.py:784-856)

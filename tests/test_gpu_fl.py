@@ -177,3 +177,67 @@ def test_hip_partials_of_two_emulated_ranks_sum_to_the_full_blend():
     r1 = agg.hip_local_partial(plan, gm.flat.data, {i: flats[i] for p, i in enumerate(ids) if p % 2 == 1}, include_global=False)
     assert (r0 + r1 - full).abs().max() <= 1e-6
     assert full.abs().max() > 0
+
+
+class RetrievalPairs(torch.utils.data.Dataset):
+    """Flickr30k-shaped test split: caps captions per image, samples are (image, tokens, image_id, ann_id, index)."""
+
+    def __init__(self, n_images, caps, seq, vocab, img_size=224):
+        self.n_images, self.caps, self.iid_to_cls = n_images, caps, None
+        self.img = det_tensor((n_images, 3, img_size, img_size), 4000, 0.5)
+        self.ids = det_ids((n_images * caps, seq), 23, vocab)
+
+    def __len__(self):
+        return self.n_images * self.caps
+
+    def __getitem__(self, i):
+        return self.img[i // self.caps], self.ids[i], 300 + 2 * (i // self.caps), 9000 + i, i
+
+
+def test_central_evaluate_retrieval_and_classification():
+    """FedavgServer._central_evaluate (fedavgserver.py:676-760): the img+txt global model through the HIP retrieval evaluator
+    (5-fold '1k' + full gallery), the uni-modal one through the forward / CE / MetricManager loop."""
+    from fedcola_amd.server.fedavgserver import FedavgServer
+    from fedcola_amd.utils import set_seed
+    from oracle import retrieval_oracle as ro
+    set_seed(3)
+    args = RefArgs(shared_param="attn", share_scope="modality", compensation=True, with_aux=False,
+                   datasets=["CIFAR100", "Flickr30k", "Coco"], modalities=["img", "img+txt", "img+txt"],
+                   out_modality_scales=[1, 1], E=1, B=4, lr=1e-3, model_name="mome_toy_patch16_224", seq_len=8, Cs=[0.5], K=2,
+                   eval_type="global", server_device="cuda", eval_batch_size=16, eval_metrics=["acc1"], criterion="CrossEntropyLoss",
+                   n_images_per_crossfold=4, n_captions_per_crossfold=20, vocab_size=30)
+    cds = [(SynthCls(8, "img", 100, seed=0),) * 2 + ("cls", "img", "CIFAR100"), (SynthPairs(8, 8, 7732),) * 2 + ("rtv", "img+txt", "Flickr30k")]
+    # (Flickr30k first: its shuffling loader then draws the first seed after torch.manual_seed, as in the re-extraction below)
+    test_sets = {"Flickr30k": RetrievalPairs(20, 5, 8, 7732), "CIFAR100": SynthCls(10, "img", 100, seed=5)}
+    srv = FedavgServer(args, None, (None, test_sets), cds, "mome_toy_patch16_224")
+    for m in srv.global_models.values():     # non-degenerate weights (default init has zero pos/cls embeddings)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        from synth import det_state_dict
+        m.load_state_dict(det_state_dict(shapes, base_seed=77))
+    srv.round = 1
+    torch.manual_seed(5)
+    out = srv._central_evaluate()
+    # retrieval: same scores as the oracle's evaluate over the features the evaluator extracted (same shuffle)
+    torch.manual_seed(5)
+    srv.evaluator.set_model(srv.global_models["Flickr30k"])
+    ex = srv.evaluator.extract_features(srv._eval_loader(test_sets["Flickr30k"], 16, True))
+    exn = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in ex.items()}
+    exp = ro.evaluate(exn, n_crossfolds=5, n_images_per_crossfold=4, n_captions_per_crossfold=20)
+    got = out["Flickr30k"]
+    for task in ("i2t", "t2i"):
+        for k, v in exp[task].items():
+            assert float(got[task][k]) == pytest.approx(v, rel=1e-12), (task, k)
+            assert float(got["n_fold"][task][k]) == pytest.approx(exp["n_fold"][task][k], rel=1e-12), ("fold", task, k)
+    assert sorted(int(v) for v in ex["image_ids"]) == [300 + 2 * i for i in range(20)]
+    # classification: loss = sum_b CE_b * |b| / N, acc1 over the whole set
+    m = srv.global_models["CIFAR100"]
+    ds = test_sets["CIFAR100"]
+    tot, hit = 0.0, 0
+    for s in range(0, len(ds), 4):
+        x, y = ds.x[s:s + 4].cuda(), ds.y[s:s + 4].cuda()
+        lg = m([x, None])[0]
+        tot += float(torch.nn.functional.cross_entropy(lg.float(), y)) * len(y)
+        hit += int((lg.argmax(-1) == y).sum())
+    res = srv.results[1]["server_evaluated_CIFAR100after"]
+    assert res["loss"] == pytest.approx(tot / len(ds), rel=1e-5)
+    assert res["metrics"]["acc1"] == pytest.approx(hit / len(ds), abs=1e-12)
