@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fedprox-mu", type=float, default=0.0, help="non-default workload: FedproxClient step (proximal term, row N3)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_child:
@@ -172,10 +173,18 @@ def main():
     sp = _lib.stream_ptr()
     step_no = [0]
 
+    if a.fedprox_mu > 0:
+        gflat = model.flat.detach().clone()
+        pscr = torch.empty(L.fc_prox_scratch_bytes(model._handle.h), dtype=torch.uint8, device=dev)
+
     def step():
         step_no[0] += 1
-        _lib.check(L.fc_client_step(model._handle.h, P(model.flat), P(grads), P(m1), P(m2), P(model._wc_or_flat()), P(img), P(ids), None,
-                                    B, seq, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, step_no[0], P(lossbuf), P(ws), ws.numel(), sp))
+        args = (model._handle.h, P(model.flat), P(grads), P(m1), P(m2), P(model._wc_or_flat()), P(img), P(ids), None,
+                B, seq, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, step_no[0], P(lossbuf), P(ws), ws.numel(), sp)
+        if a.fedprox_mu > 0:
+            _lib.check(L.fc_client_step_prox(*args, P(gflat), a.fedprox_mu, P(pscr), pscr.numel()))
+        else:
+            _lib.check(L.fc_client_step(*args))
 
     # FedAvg aggregation of the `world` concurrent clients through the product path (fedcola_amd/aggregate.py): host-computed
     # coefficient table + closed-form weights -> one HIP blend kernel per rank -> one RCCL all-reduce over xGMI
@@ -222,7 +231,8 @@ def main():
                    steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype=a.precision, data="synthetic",
                    config=dict(workload="Flickr30k FedCola, 1 img-txt client per GPU, mome_small_patch16 (ViT-S + 12x384 text tower), "
-                                        f"B={B}, 224x224 RGB, {seq}-token captions, vocab 7732, AdamW lr 1e-4, drop-path 0",
+                                        f"B={B}, 224x224 RGB, {seq}-token captions, vocab 7732, AdamW lr 1e-4, drop-path 0"
+                                        + (f", FedProx mu={a.fedprox_mu}" if a.fedprox_mu > 0 else ""),
                                global_batch=world * B, parallelism=f"{world} concurrent clients + RCCL FedAvg all-reduce"),
                    step_mfma_frac=round(pairs * PAIR_GFLOP / 1e3 / (world * PEAK_BF16_TFLOPS), 4), last_loss=round(loss, 4), enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
         if not a.no_roofline:

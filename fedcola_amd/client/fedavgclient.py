@@ -52,16 +52,21 @@ class FedavgClient(BaseClient):
         return torch.utils.data.DataLoader(dataset=dataset, batch_size=self.args.B, shuffle=shuffle)
 
     # ------------------------------------------------------------------ the hot loop (fedavgclient.py:55-116)
+    def _prox(self):
+        """(global flat copy, mu) for a proximal term, or None -- overridden by FedproxClient."""
+        return None
+
     def update(self):
         mm = MetricManager(self.eval_metrics) if self.modality != "img+txt" else MetricManager([])
         model = self.model
         model.train()
         model.to(self.device)
+        prox = self._prox()
         oargs = self._refine_optim_args(self.args)
         fused = self.args.optimizer == "AdamW" and getattr(self.args, "max_grad_norm", 0) <= 0 and \
             not getattr(self.args, "distributed", False) and not getattr(self.args, "mm_distributed", False)
         if not fused:
-            return self._update_unfused(mm, oargs)
+            return self._update_unfused(mm, oargs, prox)
         dev = model.flat.device
         n = model.flat.numel()
         grads = torch.zeros(n, device=dev)
@@ -73,6 +78,8 @@ class FedavgClient(BaseClient):
         eps = float(oargs.get("eps", 1e-8))
         wd = float(oargs.get("weight_decay", 1e-2))
         L = _lib.lib()
+        if prox is not None:
+            prox_scratch = torch.empty(L.fc_prox_scratch_bytes(model._handle.h), dtype=torch.uint8, device=dev)
         step = 0
         for e in range(self.args.E):
             num = 0
@@ -103,9 +110,13 @@ class FedavgClient(BaseClient):
                 ws = model.workspace(B, n_txt)
                 dp = model.make_droppath(B)
                 step += 1
-                check(L.fc_client_step(model._handle.h, ptr(model.flat), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(model._wc_or_flat()),
-                                       ptr(img), ptr(ids), ptr(labels), B, n_txt, ptr(dp), lr, float(betas[0]), float(betas[1]), eps, wd,
-                                       step, ptr(lossbuf), ptr(ws), ws.numel(), _lib.stream_ptr()))
+                step_args = (model._handle.h, ptr(model.flat), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(model._wc_or_flat()),
+                             ptr(img), ptr(ids), ptr(labels), B, n_txt, ptr(dp), lr, float(betas[0]), float(betas[1]), eps, wd,
+                             step, ptr(lossbuf), ptr(ws), ws.numel(), _lib.stream_ptr())
+                if prox is None:
+                    check(L.fc_client_step(*step_args))
+                else:                                                   # fedproxclient.py:64-67 inside the same fused step
+                    check(L.fc_client_step_prox(*step_args, ptr(prox[0]), float(prox[1]), ptr(prox_scratch), prox_scratch.numel()))
                 model._wc_version = model.flat._version          # fc_client_step refreshed the compute weights itself
                 if mm.metric_funcs:                                    # acc1 etc. for uni-modal clients
                     i = 0 if self.modality == "img" else 1
@@ -123,7 +134,7 @@ class FedavgClient(BaseClient):
         # the reference moves the model back to the CPU here (fedavgclient.py:114); weights stay resident in HBM instead
         return mm.results
 
-    def _update_unfused(self, mm, oargs):
+    def _update_unfused(self, mm, oargs, prox=None):
         """Any torch optimizer / gradient clipping: HIP forward+backward through autograd, torch.optim on the flat views."""
         model = self.model
         dev = model.flat.device
@@ -149,6 +160,14 @@ class FedavgClient(BaseClient):
                     inputs, targets = batch[0].to(dev), batch[1].to(dev)
                     outputs = model([None, inputs])[1]
                     loss = self.criterion()(outputs, targets)
+                if prox is not None:                                    # fedproxclient.py:64-67 (un-squared per-tensor norms)
+                    term = 0.
+                    for k, sgm in model.segments.items():
+                        if not sgm["trainable"]:
+                            continue
+                        sl = slice(sgm["offset"], sgm["offset"] + sgm["numel"])
+                        term = term + (model.flat[sl] - prox[0][sl]).norm(2)
+                    loss = loss + prox[1] * (0.5 * term)
                 loss.backward()
                 params = list(model.parameters())                      # refreshes the .grad views
                 if getattr(self.args, "max_grad_norm", 0) > 0:

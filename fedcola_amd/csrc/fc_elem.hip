@@ -775,3 +775,63 @@ int fc_scale_segments_impl(float* buf, const int64_t* seg_off, const int64_t* se
   FC_LAUNCH_CHECK();
   return 0;
 }
+
+// ======================================================================== FedProx proximal term (fedproxclient.py:64-67)
+__device__ inline float block_sum_256(float v, float* red) {   // fixed tree: the same order on every run
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;
+}
+__global__ void __launch_bounds__(256) k_prox_partial(const float* __restrict__ p, const float* __restrict__ g, const FcProxChunk* __restrict__ chunks,
+                                                      float* __restrict__ partial) {
+  __shared__ float red[4];
+  const FcProxChunk c = chunks[blockIdx.x];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < c.n; i += 256) {
+    const float d = p[c.offset + i] - g[c.offset + i];
+    acc += d * d;
+  }
+  const float r = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+// block s: norm[s]; the last block to finish (a counter would do) is avoided: a second single-block launch sums the norms
+__global__ void __launch_bounds__(256) k_prox_norm(const float* __restrict__ partial, const int32_t* __restrict__ first, float* __restrict__ norm) {
+  __shared__ float red[4];
+  const int s = blockIdx.x;
+  float acc = 0.f;
+  for (int c = first[s] + threadIdx.x; c < first[s + 1]; c += 256) acc += partial[c];
+  const float r = block_sum_256(acc, red);
+  if (threadIdx.x == 0) norm[s] = sqrtf(r);
+}
+__global__ void __launch_bounds__(256) k_prox_loss(const float* __restrict__ norm, int nseg, float mu, int B, float* __restrict__ lossbuf) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int s = threadIdx.x; s < nseg; s += 256) acc += norm[s];
+  const float r = block_sum_256(acc, red);
+  if (threadIdx.x == 0) {
+    const float v = mu * (0.5f * r);
+    lossbuf[1] += v;
+    lossbuf[0] += v * (float)B;
+  }
+}
+__global__ void __launch_bounds__(256) k_prox_grad(const float* __restrict__ p, const float* __restrict__ g, const FcProxChunk* __restrict__ chunks,
+                                                   const float* __restrict__ norm, float mu, float* __restrict__ grads) {
+  const FcProxChunk c = chunks[blockIdx.x];
+  const float nr = norm[c.seg];
+  if (!(nr > 0.f)) return;                      // torch's norm backward: zero gradient at a zero norm
+  const float coef = (mu * 0.5f) / nr;
+  for (int i = threadIdx.x; i < c.n; i += 256) grads[c.offset + i] += coef * (p[c.offset + i] - g[c.offset + i]);
+}
+int fc_prox_term_impl(const float* p, const float* g, const FcProxChunk* chunks, int nchunks, const int32_t* first, int nseg, float* partial,
+                      float* norm, float mu, int B, float* grads, float* lossbuf, hipStream_t s) {
+  if (nchunks <= 0 || nseg <= 0) return 0;
+  hipLaunchKernelGGL(k_prox_partial, dim3(nchunks), dim3(256), 0, s, p, g, chunks, partial);
+  hipLaunchKernelGGL(k_prox_norm, dim3(nseg), dim3(256), 0, s, partial, first, norm);
+  hipLaunchKernelGGL(k_prox_loss, dim3(1), dim3(256), 0, s, norm, nseg, mu, B, lossbuf);
+  hipLaunchKernelGGL(k_prox_grad, dim3(nchunks), dim3(256), 0, s, p, g, chunks, norm, mu, grads);
+  FC_LAUNCH_CHECK();
+  return 0;
+}

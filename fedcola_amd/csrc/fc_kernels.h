@@ -68,6 +68,15 @@ int fc_colsum(int dt, const void* dy, float* db, int M, int N, int accumulate, h
 // (host-computed closed-form weights; src_off < 0: client j does not hold that key).  All tables are device arrays.
 int fc_blend_segments(float* out, const float* g, const float* const* bases, int m, const int64_t* seg_off, const int64_t* seg_len,
                       const int64_t* src_off, const float* seg_w, int nseg, hipStream_t s);
+// FedProx proximal term over parameter tensors (fedproxclient.py:64-67).  One FcProxChunk per <= FC_PROX_CHUNK consecutive elements
+// of a parameter tensor; seg = dense index of the tensor among those that take part.
+#define FC_PROX_CHUNK 16384
+struct FcProxChunk { int64_t offset; int32_t n; int32_t seg; };
+// partial[c] = sum((p-g)^2) of chunk c; norm[s] = sqrt(sum of its chunks' partials) (chunks of a tensor are consecutive: first[s] ..
+// first[s+1]); loss accumulators += 0.5*mu*sum(norm) (lossbuf[1]) and that times B (lossbuf[0]); grads += 0.5*mu*(p-g)/norm (0 if norm == 0).
+// Fixed reduction order throughout: bitwise reproducible.
+int fc_prox_term_impl(const float* p, const float* g, const FcProxChunk* chunks, int nchunks, const int32_t* first, int nseg, float* partial,
+                      float* norm, float mu, int B, float* grads, float* lossbuf, hipStream_t s);
 int fc_scale_segments_impl(float* buf, const int64_t* seg_off, const int64_t* seg_len, const float* seg_w, int nseg, hipStream_t s);
 
 // ---- generic strided GEMM (any shape; fp32 accumulate).  C[m,n] = epi( sum_k A(m,k)*B(k,n) )

@@ -46,6 +46,8 @@ struct fc_model {
   mutable std::vector<FcTnProblem> probs_host;   // last uploaded grouped-GEMM table (+ where it lives on the device)
   mutable const void* probs_dev = nullptr;
   mutable std::vector<FcLnReduce> ln_host;        // same for the grouped LayerNorm-gradient reduction
+  mutable std::vector<char> prox_host;            // same for the FedProx chunk table
+  mutable const void* prox_dev = nullptr;
   mutable const void* ln_dev = nullptr;
   // the two towers are independent until the loss: the text tower runs on a side stream, forked/joined with events
   mutable hipStream_t side = nullptr;
@@ -892,10 +894,75 @@ extern "C" int fc_adamw_step(const fc_model_t* m, float* params, float* grads, f
 // every step at fedavgclient.py:95, so the temperature never trains)
 static float contrastive_tau() { return expf(fminf(fmaxf(logf(1.0f / 0.07f), 0.0f), logf(100.0f))); }
 
+// ---- FedProx proximal term (src/client/fedproxclient.py:64-67) over the trainable parameter tensors
+static void prox_tables(const fc_model* m, std::vector<FcProxChunk>& chunks, std::vector<int32_t>& first) {
+  int seg = 0;
+  first.clear();
+  chunks.clear();
+  for (const fc_segment& sg : m->segs) {
+    if (!sg.trainable || sg.numel <= 0) continue;   // a frozen tensor never leaves its global value: norm 0, no contribution
+    first.push_back((int32_t)chunks.size());
+    for (int64_t o = 0; o < sg.numel; o += FC_PROX_CHUNK)
+      chunks.push_back(FcProxChunk{sg.offset + o, (int32_t)std::min<int64_t>(FC_PROX_CHUNK, sg.numel - o), seg});
+    ++seg;
+  }
+  first.push_back((int32_t)chunks.size());
+}
+static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+extern "C" size_t fc_prox_scratch_bytes(const fc_model_t* m) {
+  std::vector<FcProxChunk> ch;
+  std::vector<int32_t> first;
+  prox_tables(m, ch, first);
+  return align16(ch.size() * sizeof(FcProxChunk)) + align16(first.size() * sizeof(int32_t)) + align16(ch.size() * sizeof(float)) +
+         align16(first.size() * sizeof(float));
+}
+extern "C" int fc_prox_term(const fc_model_t* m, const float* params, const float* global_params, float mu, int32_t B, float* grads, float* lossbuf,
+                            void* scratch, size_t scratch_bytes, void* stream) {
+  FC_REQUIRE(params && global_params && grads && lossbuf && scratch, "fc_prox_term: null buffer");
+  FC_REQUIRE(scratch_bytes >= fc_prox_scratch_bytes(m), "fc_prox_term: scratch too small (%zu < %zu)", scratch_bytes, fc_prox_scratch_bytes(m));
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<FcProxChunk> ch;
+  std::vector<int32_t> first;
+  prox_tables(m, ch, first);
+  const size_t b0 = align16(ch.size() * sizeof(FcProxChunk)), b1 = align16(first.size() * sizeof(int32_t)), b2 = align16(ch.size() * sizeof(float));
+  char* base = (char*)scratch;
+  std::vector<char> img(b0 + b1, 0);
+  memcpy(img.data(), ch.data(), ch.size() * sizeof(FcProxChunk));
+  memcpy(img.data() + b0, first.data(), first.size() * sizeof(int32_t));
+  if (!(m->prox_dev == scratch && m->prox_host == img)) {     // tables are uploaded once per (scratch, trainable set)
+    FC_CHECK_HIP(hipStreamSynchronize(s));
+    m->prox_host = img;
+    m->prox_dev = scratch;
+    FC_CHECK_HIP(hipMemcpyAsync(base, m->prox_host.data(), m->prox_host.size(), hipMemcpyHostToDevice, s));
+  }
+  return fc_prox_term_impl(params, global_params, (const FcProxChunk*)base, (int)ch.size(), (const int32_t*)(base + b0), (int)first.size() - 1,
+                           (float*)(base + b0 + b1), (float*)(base + b0 + b1 + b2), mu, B, grads, lossbuf, s);
+}
+
+static int client_step_impl(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
+                            const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
+                            void* stream, const float* global_params, float mu, void* prox_scratch, size_t prox_scratch_bytes);
 extern "C" int fc_client_step(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
                               const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
                               void* stream) {
+  return client_step_impl(m, params, grads, exp_avg, exp_avg_sq, wc, img, ids, labels, B, n_txt, droppath, lr, beta1, beta2, eps, weight_decay, step,
+                          lossbuf, workspace, workspace_bytes, stream, nullptr, 0.f, nullptr, 0);
+}
+extern "C" int fc_client_step_prox(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
+                                   const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace,
+                                   size_t workspace_bytes, void* stream, const float* global_params, float mu, void* prox_scratch,
+                                   size_t prox_scratch_bytes) {
+  FC_REQUIRE(global_params && prox_scratch, "fc_client_step_prox: null global parameters / scratch");
+  return client_step_impl(m, params, grads, exp_avg, exp_avg_sq, wc, img, ids, labels, B, n_txt, droppath, lr, beta1, beta2, eps, weight_decay, step,
+                          lossbuf, workspace, workspace_bytes, stream, global_params, mu, prox_scratch, prox_scratch_bytes);
+}
+static int client_step_impl(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
+                            const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
+                            void* stream, const float* global_params, float mu, void* prox_scratch, size_t prox_scratch_bytes) {
   hipStream_t s = (hipStream_t)stream;
   FC_REQUIRE(grads && exp_avg && exp_avg_sq && lossbuf, "fc_client_step: null buffer");
   FC_REQUIRE(step >= 1, "fc_client_step: step is 1-based");
@@ -917,6 +984,8 @@ extern "C" int fc_client_step(const fc_model_t* m, float* params, float* grads, 
     (i == 0 ? d0 : d1) = w.dout[i];
   }
   FC_TRY(backward_impl(m, params, wc, d0, d1, grads, w, s));
+  if (global_params)   // FedproxClient.update: loss += mu * 0.5 * sum ||p - p_global||, before the optimizer step (fedproxclient.py:64-72)
+    FC_TRY(fc_prox_term(m, params, global_params, mu, B, grads, lossbuf, prox_scratch, prox_scratch_bytes, stream));
   // compute weights for the next step: without re-param linears and with every segment trainable the bf16 shadow is written
   // by the AdamW kernel itself (one pass over the parameters instead of two)
   bool has_aux = false, all_trainable = true;

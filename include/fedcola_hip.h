@@ -100,6 +100,20 @@ int fc_client_step(const fc_model_t* m, float* params, float* grads, float* exp_
                    const float* droppath, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float* lossbuf, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- FedproxClient.update (src/client/fedproxclient.py:29-92): the same loop with the proximal term
+ *   loss += mu * 0.5 * sum over parameter tensors of ||param - global_param||_2        (fedproxclient.py:64-67; UN-squared norms)
+ * global_params: flat float32 copy of the parameters taken when update() starts (copy.deepcopy(self.model), :33).
+ * fc_prox_term adds 0.5*mu*(p-g)/||p-g|| per tensor to grads (0 where the norm is 0, like torch's norm backward) and the term's
+ * value to lossbuf ([1] += v, [0] += v*B); fc_client_step_prox = fc_client_step with that term between backward and AdamW.step.
+ * scratch: fc_prox_scratch_bytes(m) bytes of device memory (chunk tables + partial sums; fixed reduction order). */
+size_t fc_prox_scratch_bytes(const fc_model_t* m);
+int fc_prox_term(const fc_model_t* m, const float* params, const float* global_params, float mu, int32_t B, float* grads, float* lossbuf,
+                 void* scratch, size_t scratch_bytes, void* stream);
+int fc_client_step_prox(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
+                        const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
+                        void* stream, const float* global_params, float mu, void* prox_scratch, size_t prox_scratch_bytes);
+
 /* ---- FedavgServer._aggregate blend (fedavgserver.py:656-664) in closed form, per state_dict key (segment):
  * out[seg_offset[s] + i] = w[s][0]*global[seg_offset[s] + i] + sum_j w[s][1+j] * client_bases[j][src_offset[s][j] + i].
  * Clients of other datasets hold the key at another offset of their own flat buffer (src_offset, < 0: key absent).

@@ -384,10 +384,25 @@ def trainable_keys(p: Dict[str, Tensor], cfg: OracleCfg) -> List[str]:
     return out
 
 
-def client_step(p, cfg: OracleCfg, batch, state, lr: float, weight_decay: float = 0.0, dp_masks=None):
+def prox_term(p: Dict[str, Tensor], g: Dict[str, Tensor], mu: float, keys: Sequence[str]):
+    """FedproxClient.update's proximal term (src/client/fedproxclient.py:64-67):
+        prox = sum over named parameters of ||param - global_param||_2   (per-tensor, UN-squared);   loss += mu * (0.5 * prox)
+    Returns (mu*0.5*prox, {key: d/dparam}).  torch's norm backward yields 0 where the norm is 0 (first step: param == global)."""
+    total = 0.0
+    grads = {}
+    for k in keys:
+        d = p[k] - g[k]
+        nrm = d.norm(2)
+        total = total + nrm
+        grads[k] = (mu * 0.5) * d / nrm if float(nrm) > 0 else torch.zeros_like(d)
+    return mu * (0.5 * total), grads
+
+
+def client_step(p, cfg: OracleCfg, batch, state, lr: float, weight_decay: float = 0.0, dp_masks=None, prox=None):
     """One iteration of FedavgClient.update's batch loop (fedavgclient.py:79-102):
     zero_grad -> fwd -> loss -> bwd -> AdamW.step.  ``state`` = {'step': int, 'm': {k}, 'v': {k}}.
-    batch: ('img+txt', img, ids) | ('img', img, y) | ('txt', ids, y).  Returns (loss, outs, grads)."""
+    batch: ('img+txt', img, ids) | ('img', img, y) | ('txt', ids, y).  Returns (loss, outs, grads).
+    prox = (global_params, mu): FedproxClient.update (fedproxclient.py:64-67) -- the proximal term joins loss and grads."""
     kind = batch[0]
     if kind == "img+txt":
         outs, cache = forward(p, cfg, [batch[1], batch[2]], feat_out=True, dp_masks=dp_masks)
@@ -402,6 +417,15 @@ def client_step(p, cfg: OracleCfg, batch, state, lr: float, weight_decay: float 
         loss, dl = cross_entropy(outs[1], batch[2])
         d_outs = [None, dl]
     grads = backward(p, cfg, cache, d_outs)
+    if prox is not None:
+        keys = [k for k in p if p[k].dtype.is_floating_point]          # named_parameters(): every nn.Parameter
+        pv, pg = prox_term(p, prox[0], prox[1], keys)
+        loss = loss + pv
+        for k, v in pg.items():
+            if k in grads:
+                grads[k] = grads[k] + v
+            elif float(v.abs().max()) > 0:
+                grads[k] = v
     state["step"] += 1
     for k in trainable_keys(p, cfg):
         if k not in grads:          # parameter without grad: torch optimizers skip it

@@ -7,6 +7,7 @@ place through tests/refstub.py).  Run in the build container only:
 Outputs (tests/golden/):
     model_<case>.json   forward outputs, loss, gradient / post-AdamW fingerprints (full tensors for the toy case)
     update_toy.json     FedavgClient.update() result dict + final weights fingerprint
+    update_prox_toy.json  the same for FedproxClient.update() (mu = 0.5)
     agg.json            FedavgServer._aggregate outputs over the scope / compensation matrix
     sampling.json       FedavgServer._sample_clients id lists
     init.json           default-init state_dict fingerprints under torch.manual_seed (factory order check)
@@ -146,6 +147,24 @@ def update_case():
     with open(os.path.join(HERE, "update_toy.json"), "w") as f:
         json.dump(rec, f)
     print("update", res)
+
+
+def update_prox_case():
+    """FedproxClient.update() (src/client/fedproxclient.py) on the toy img+txt model: 2 epochs x 3 batches, mu = 0.5."""
+    c = CASES["toy"]
+    args = RefArgs(E=2, B=4, lr=1e-3, optimizer="AdamW", no_shuffle=True, mu=0.5)
+    ds = SynthPairs(10, 8, 30)
+    cl = ref.fedproxclient.FedproxClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt",
+                                         eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cpu"
+    cl.download({"Flickr30k": build(c["mk"])})
+    res = cl.update()
+    sd = cl.upload()
+    rec = dict(results={str(k): v for k, v in res.items()}, n=10, B=4, E=2, lr=1e-3, mu=0.5,
+               after={k: pack(v, True) for k, v in sd.items() if v.dtype.is_floating_point})
+    with open(os.path.join(HERE, "update_prox_toy.json"), "w") as f:
+        json.dump(rec, f)
+    print("update prox", res)
 
 
 # ----------------------------------------------------------------------------------------- aggregation
@@ -307,9 +326,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "retrieval":
         retrieval_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "prox":
+        update_prox_case()
+        sys.exit(0)
     for n, c in CASES.items():
         model_case(n, c)
     update_case()
+    update_prox_case()
     agg_case()
     sampling_case()
     init_case()

@@ -95,8 +95,9 @@ def load_reference():
     import src.models.mome as mome
     import src.client.fedavgclient as fedavgclient
     import src.server.fedavgserver as fedavgserver
+    import src.client.fedproxclient as fedproxclient
 
-    ns = types.SimpleNamespace(mome=mome, fedavgclient=fedavgclient, fedavgserver=fedavgserver,
+    ns = types.SimpleNamespace(mome=mome, fedavgclient=fedavgclient, fedavgserver=fedavgserver, fedproxclient=fedproxclient,
                                create_model=create_model, registry=registry, DropPath=DropPath)
     _loaded["ns"] = ns
     return ns

@@ -241,3 +241,67 @@ def test_central_evaluate_retrieval_and_classification():
     res = srv.results[1]["server_evaluated_CIFAR100after"]
     assert res["loss"] == pytest.approx(tot / len(ds), rel=1e-5)
     assert res["metrics"]["acc1"] == pytest.approx(hit / len(ds), abs=1e-12)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_fedprox_update_matches_reference_result_dict(fused):
+    """N3: FedproxClient.update (fused fc_client_step_prox / unfused torch path) against the reference's FedproxClient.update golden."""
+    from fedcola_amd.client.fedproxclient import FedproxClient
+    rec = G.load("update_prox_toy.json")
+    args = RefArgs(E=rec["E"], B=rec["B"], lr=rec["lr"], optimizer="AdamW", no_shuffle=True, max_grad_norm=0.0 if fused else 1e9, mu=rec["mu"],
+                   algorithm="fedprox")
+    ds = SynthPairs(rec["n"], 8, 30)
+    cl = FedproxClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cuda"
+    cl.download({"Flickr30k": toy_model()})
+    res = cl.update()
+    plain = G.load("update_toy.json")["results"]
+    for e in (1, 2):
+        assert abs(res[e]["loss"] - rec["results"][str(e)]["loss"]) <= 3e-4, (e, res[e], rec["results"][str(e)])
+        assert abs(res[e]["loss"] - plain[str(e)]["loss"]) > 1e-2          # the term is really in there
+    sd = cl.upload()
+    for k, r in rec["after"].items():
+        exp = torch.tensor(r["full"]).reshape(r["shape"])
+        err = (sd[k].cpu() - exp).abs()
+        if k.endswith("attn.qkv.bias"):
+            D = exp.numel() // 3
+            err[D:2 * D] = 0
+        assert err.max() <= 2.5e-3, k
+
+
+def test_prox_term_kernel_vs_oracle():
+    """fc_prox_term: per-tensor un-squared norms, zero-norm tensors (gradient 0), frozen tensors skipped, loss accumulators."""
+    from fedcola_amd import _lib
+    from oracle import mome_oracle as O
+    m = toy_model()
+    L = _lib.lib()
+    g = m.flat.detach().clone()
+    torch.manual_seed(0)
+    p = g + 0.01 * torch.randn_like(g)
+    keys = list(m.segments.keys())
+    same = keys[3]                                   # this tensor has not moved: norm 0
+    s3 = m.segments[same]
+    p[s3["offset"]: s3["offset"] + s3["numel"]] = g[s3["offset"]: s3["offset"] + s3["numel"]]
+    frozen = keys[5]
+    _lib.check(L.fc_model_set_trainable(m._handle.h, m.segments[frozen]["index"], 0))
+    grads = torch.zeros_like(g)
+    lossbuf = torch.zeros(2, device="cuda")
+    scratch = torch.empty(L.fc_prox_scratch_bytes(m._handle.h), dtype=torch.uint8, device="cuda")
+    mu, B = 0.3, 4
+    for _ in range(2):                                # second call: cached tables, accumulating outputs
+        _lib.check(L.fc_prox_term(m._handle.h, _lib.ptr(p), _lib.ptr(g), mu, B, _lib.ptr(grads), _lib.ptr(lossbuf), _lib.ptr(scratch),
+                                  scratch.numel(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    view = lambda flat, k: flat[m.segments[k]["offset"]: m.segments[k]["offset"] + m.segments[k]["numel"]].cpu()
+    pk = {k: view(p, k) for k in keys if k != frozen}
+    gk = {k: view(g, k) for k in keys if k != frozen}
+    val, gr = O.prox_term(pk, gk, mu, list(pk.keys()))
+    assert float(lossbuf[1]) == pytest.approx(2 * float(val), rel=1e-5)
+    assert float(lossbuf[0]) == pytest.approx(2 * B * float(val), rel=1e-5)
+    for k in keys:
+        got = view(grads, k)
+        if k == frozen or k == same:
+            assert float(got.abs().max()) == 0.0, k
+        else:
+            assert (got - 2 * gr[k]).abs().max() <= 1e-5 * max(1e-3, float(gr[k].abs().max())), k
+    _lib.check(L.fc_model_set_trainable(m._handle.h, m.segments[frozen]["index"], 1))

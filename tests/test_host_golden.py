@@ -118,6 +118,42 @@ def test_update_result_schema_oracle_vs_golden():
         assert rec["results"][str(e + 1)]["metrics"] == {}
 
 
+def test_fedprox_update_oracle_vs_golden():
+    """N3: the oracle loop with the proximal term (un-squared per-tensor norms) reproduces FedproxClient.update()'s result dict
+    and the post-update weights of the reference (tests/golden/update_prox_toy.json)."""
+    from oracle import mome_oracle as O
+    from synth import det_ids, det_tensor
+    from test_oracle_golden import cfg_from_mk
+    rec = G.load("update_prox_toy.json")
+    cfg = cfg_from_mk(G.load("model_toy.json")["mk"])
+    p = G.case_weights("toy")
+    glob = {k: v.clone() for k, v in p.items()}
+    img = det_tensor((rec["n"], 3, 224, 224), 2000, 0.5)
+    ids = det_ids((rec["n"], 8), 11, 30)
+    state = dict(step=0, m={}, v={})
+    for e in range(rec["E"]):
+        tot = 0.0
+        for b0 in range(0, rec["n"], rec["B"]):
+            sl = slice(b0, min(rec["n"], b0 + rec["B"]))
+            loss, _, _ = O.client_step(p, cfg, ("img+txt", img[sl], ids[sl]), state, lr=rec["lr"], prox=(glob, rec["mu"]))
+            tot += float(loss) * (sl.stop - sl.start)
+        assert abs(tot / rec["n"] - rec["results"][str(e + 1)]["loss"]) <= 2e-4
+    # the proximal term changes the trajectory: the plain-FedAvg golden losses differ by > 1e-2
+    assert abs(rec["results"]["2"]["loss"] - G.load("update_toy.json")["results"]["2"]["loss"]) > 1e-2
+    for k, r in rec["after"].items():
+        exp = torch.tensor(r["full"]).reshape(r["shape"])
+        err = (p[k] - exp).abs()
+        if k.endswith("attn.qkv.bias"):
+            D = exp.numel() // 3
+            err[D:2 * D] = 0          # exactly-zero true gradient of the key bias (see golden_util)
+        assert err.max() <= 2.5e-3, k
+    # value / gradient of the term itself, incl. the zero-norm case (first step: param == global -> gradient 0)
+    a = {"w": torch.tensor([3.0, 4.0]), "b": torch.tensor([1.0])}
+    g0 = {"w": torch.tensor([0.0, 0.0]), "b": torch.tensor([1.0])}
+    v, gr = O.prox_term(a, g0, 0.5, ["w", "b"])
+    assert float(v) == pytest.approx(0.5 * 0.5 * 5.0) and torch.allclose(gr["w"], torch.tensor([0.15, 0.2])) and float(gr["b"].abs().max()) == 0
+
+
 def test_c_abi_exports_every_declared_symbol():
     from fedcola_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "fedcola_hip.h")).read()
