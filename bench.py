@@ -148,12 +148,18 @@ def main():
     cpu_base = None
     if world == 1 and not a.no_cpu_baseline:
         cpu_base = cpu_baseline(a.batch, Args.seq_len, Args.vocab_size)      # before any GPU call in this process
+    if os.environ.get("FC_BENCH_ONE_DEVICE"):      # validation of the N>1 code path on a 1-GPU box: every rank on cuda:0
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FC_BENCH_BACKEND", "nccl")               # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from fedcola_amd import _lib
     from fedcola_amd.mome import create_model
     args = Args()
@@ -192,10 +198,10 @@ def main():
     if world > 1:
         from fedcola_amd import aggregate as agg
         import copy
-        ids = list(range(world))
+        cids = list(range(world))                                          # one client per rank
         keys = list(model.required_params().keys())
-        coef = {k: {i: 1.0 / world for i in ids} for k in keys}            # equal client sizes, scope 'dataset'
-        plan = agg.build_plan(model, ids, coef, {i: model.segments for i in ids})
+        coef = {k: {i: 1.0 / world for i in cids} for k in keys}           # equal client sizes, scope 'dataset'
+        plan = agg.build_plan(model, cids, coef, {i: model.segments for i in cids})
         global_model = copy.deepcopy(model)
 
     def aggregate():
@@ -203,6 +209,7 @@ def main():
             agg.aggregate(global_model, plan, {rank: model.flat.data}, rank=rank, world=world)
             model.flat.data.copy_(global_model.flat.data)                  # next round's download(): device-to-device
             model._bump()
+            model.prepare_weights(force=True)                              # ... and its bf16 compute weights
 
     def barrier():
         if world > 1:
