@@ -178,6 +178,22 @@ def hip_local_partial(plan: BlendPlan, global_flat: torch.Tensor, local_flats: M
     return out
 
 
+def _copy_runs(plan: BlendPlan):
+    """Planned segments merged into maximal runs: neighbours separated only by alignment padding (< 64 elements, so no unplanned
+    segment can sit in between) are copied together -- a handful of device copies instead of one per state_dict key."""
+    runs = getattr(plan, "_runs", None)
+    if runs is None:
+        segs = sorted((int(o), int(o) + int(n)) for o, n in zip(plan.seg_off.tolist(), plan.seg_len.tolist()))
+        runs = []
+        for o, e in segs:
+            if runs and 0 <= o - runs[-1][1] < 64:
+                runs[-1][1] = e
+            else:
+                runs.append([o, e])
+        plan._runs = runs
+    return runs
+
+
 def aggregate(global_model, plan: BlendPlan, local_flats: Mapping[int, torch.Tensor], *, rank: int = 0, world: int = 1,
               all_reduce: Optional[Callable[[torch.Tensor], None]] = None, local_partial=hip_local_partial):
     """Blend into ``global_model`` in place.  With world > 1 every rank contributes the clients it trained and the
@@ -189,8 +205,7 @@ def aggregate(global_model, plan: BlendPlan, local_flats: Mapping[int, torch.Ten
             import torch.distributed as dist
             all_reduce = dist.all_reduce
         all_reduce(partial)
-    for s in range(len(plan.keys)):                      # only the planned (required_params) segments are replaced
-        o, n = int(plan.seg_off[s]), int(plan.seg_len[s])
-        g[o:o + n].copy_(partial[o:o + n])
+    for o, e in _copy_runs(plan):                        # only the planned (required_params) segments are replaced
+        g[o:e].copy_(partial[o:e])
     global_model._bump()
     return global_model
