@@ -54,16 +54,18 @@ struct fc_model {
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // weight gradients are launched in chunks (every few layers) on their own stream, under the rest of the backward
   mutable hipStream_t dws = nullptr;
-  mutable hipEvent_t ev_dw_in = nullptr, ev_dw_in2 = nullptr, ev_dw_out = nullptr;
+  mutable hipEvent_t ev_dw_in = nullptr, ev_dw_in2[3] = {nullptr, nullptr, nullptr}, ev_dw_out = nullptr;
   // second micro-batch of the image tower
-  mutable hipStream_t mbs = nullptr;
-  mutable hipEvent_t ev_mb_join = nullptr;
+  mutable hipStream_t mbs[3] = {nullptr, nullptr, nullptr};      // micro-batch chains 1..3 (chain 0 runs on the caller's stream)
+  mutable hipEvent_t ev_mb_join[3] = {nullptr, nullptr, nullptr};
   ~fc_model() {
     if (dws) (void)hipStreamDestroy(dws);
     if (ev_dw_in) (void)hipEventDestroy(ev_dw_in);
-    if (ev_dw_in2) (void)hipEventDestroy(ev_dw_in2);
-    if (mbs) (void)hipStreamDestroy(mbs);
-    if (ev_mb_join) (void)hipEventDestroy(ev_mb_join);
+    for (int k = 0; k < 3; ++k) {
+      if (ev_dw_in2[k]) (void)hipEventDestroy(ev_dw_in2[k]);
+      if (mbs[k]) (void)hipStreamDestroy(mbs[k]);
+      if (ev_mb_join[k]) (void)hipEventDestroy(ev_mb_join[k]);
+    }
     if (ev_dw_out) (void)hipEventDestroy(ev_dw_out);
     if (side) (void)hipStreamDestroy(side);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -292,11 +294,11 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
     t.dh = bp.take((size_t)t.M * D * es);
     t.dO = bp.take((size_t)t.M * D * es);
     t.delta = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * t.N);
-    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)2 * 2 * c.depth * fc_layernorm_bwd_partial_blocks(t.M) * 2 * D);   // x2: micro-batches
+    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)4 * 2 * c.depth * fc_layernorm_bwd_partial_blocks(t.M) * 2 * D);   // x4: micro-batches
   }
   w.max_probs = 2 * (4 * c.depth + 1);
   w.probs = (FcTnProblem*)bp.take(sizeof(FcTnProblem) * w.max_probs);
-  w.max_ln = 8 * c.depth;
+  w.max_ln = 12 * c.depth;
   w.lntab = (FcLnReduce*)bp.take(sizeof(FcLnReduce) * w.max_ln);
   w.loss_scratch = (float*)bp.take(sizeof(float) * (2 * (size_t)B * B + 2 * B + 64));
   w.bytes = bp.off;
@@ -348,7 +350,11 @@ static Ws slice_ws(const fc_model* m, const Ws& w, int i, int b0, int bn, int mb
 }
 static int microbatches(const fc_model* m, int B) {
   static int req = getenv("FC_MICROBATCH") ? atoi(getenv("FC_MICROBATCH")) : 2;
-  return (m->dt == FC_BF16 && req >= 2 && B >= 16) ? 2 : 1;
+  if (m->dt != FC_BF16 || req < 2 || B < 16) return 1;
+  int n = req > 4 ? 4 : req;
+  if (B < 8 * n) n = 2;
+  while (n > 1 && !m->mbs[n - 2]) --n;      // streams are created for the configured count only
+  return n;
 }
 
 extern "C" size_t fc_workspace_bytes(const fc_model_t* m, int32_t B, int32_t n_txt) {
@@ -402,7 +408,7 @@ struct Ctx {
   std::vector<FcTnProblem>* defer = nullptr;   // non-null: weight/bias gradients are queued for the grouped launch
   struct DwState* dw = nullptr;                // chunked early launches of the queued problems
   bool no_wgrad = false;                       // micro-batch slice: the full-batch weight gradients are queued by the driver
-  hipStream_t s2nd = nullptr;                  // flush_dw also orders the chunk after this stream (second micro-batch)
+  int n_more = 0;                              // flush_dw also orders the chunk after the other micro-batch chains' streams
   std::vector<FcLnReduce>* lnq = nullptr;      // non-null: LayerNorm dgamma/dbeta partials are queued likewise
   int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res, void* dx, float* dg,
              float* db, int M, int D, float* partial) const {
@@ -532,9 +538,14 @@ static int ensure_side(const fc_model* m) {
   if (!m->dws) {
     FC_CHECK_HIP(hipStreamCreateWithFlags(&m->dws, hipStreamNonBlocking));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in, hipEventDisableTiming));
-    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in2, hipEventDisableTiming));
-    FC_CHECK_HIP(hipStreamCreateWithFlags(&m->mbs, hipStreamNonBlocking));
-    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_mb_join, hipEventDisableTiming));
+    // (HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default: caller + text + dW + one extra chain
+    // fill them; streams beyond that share a queue and serialise, so only the chains that are used get a stream)
+    static int req = getenv("FC_MICROBATCH") ? atoi(getenv("FC_MICROBATCH")) : 2;
+    for (int k = 0; k < 3 && k < (req > 4 ? 4 : req) - 1; ++k) {
+      FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in2[k], hipEventDisableTiming));
+      FC_CHECK_HIP(hipStreamCreateWithFlags(&m->mbs[k], hipStreamNonBlocking));
+      FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_mb_join[k], hipEventDisableTiming));
+    }
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_out, hipEventDisableTiming));
   }
   if (!m->side) {
@@ -548,14 +559,16 @@ static int fork_side(const fc_model* m, hipStream_t s) {   // side (text tower) 
   FC_TRY(ensure_side(m));
   FC_CHECK_HIP(hipEventRecord(m->ev_fork, s));
   FC_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-  FC_CHECK_HIP(hipStreamWaitEvent(m->mbs, m->ev_fork, 0));
+  for (int k = 0; k < 3 && m->mbs[k]; ++k) FC_CHECK_HIP(hipStreamWaitEvent(m->mbs[k], m->ev_fork, 0));
   return 0;
 }
 static int join_side(const fc_model* m, hipStream_t s) {
   FC_CHECK_HIP(hipEventRecord(m->ev_join, m->side));
   FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
-  FC_CHECK_HIP(hipEventRecord(m->ev_mb_join, m->mbs));
-  FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_mb_join, 0));
+  for (int k = 0; k < 3 && m->mbs[k]; ++k) {
+    FC_CHECK_HIP(hipEventRecord(m->ev_mb_join[k], m->mbs[k]));
+    FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_mb_join[k], 0));
+  }
   return 0;
 }
 
@@ -583,15 +596,17 @@ static int forward_impl(const fc_model* m, const float* params, const void* wc, 
     Ctx c2 = c;
     c2.s = m->side;
     FC_TRY(tower_forward(c2, w, 1, nullptr, ids, feat_out, out_txt));
-    if (microbatches(m, B) == 2) {
-      const int b1 = B / 2;
+    const int nmb = microbatches(m, B);
+    if (nmb > 1) {
       const size_t ipx = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
       const size_t ow = (size_t)((feat_out || m->tw[0].task == FC_TASK_RTV) ? m->cfg.dim : m->tw[0].ncls);
-      Ws wa = slice_ws(m, w, 0, 0, b1, 0), wb = slice_ws(m, w, 0, b1, B - b1, 1);
-      Ctx cb = c;
-      cb.s = m->mbs;
-      FC_TRY(tower_forward(c, wa, 0, img, nullptr, feat_out, out_img));
-      FC_TRY(tower_forward(cb, wb, 0, img + (size_t)b1 * ipx, nullptr, feat_out, out_img ? out_img + (size_t)b1 * ow : nullptr));
+      for (int k = 0; k < nmb; ++k) {
+        const int b0 = (int)((long)B * k / nmb), b1 = (int)((long)B * (k + 1) / nmb);
+        Ws wk = slice_ws(m, w, 0, b0, b1 - b0, k);
+        Ctx ck = c;
+        if (k > 0) ck.s = m->mbs[k - 1];
+        FC_TRY(tower_forward(ck, wk, 0, img + (size_t)b0 * ipx, nullptr, feat_out, out_img ? out_img + (size_t)b0 * ow : nullptr));
+      }
     } else {
       FC_TRY(tower_forward(c, w, 0, img, nullptr, feat_out, out_img));
     }
@@ -659,9 +674,9 @@ static int flush_dw(const Ctx& c) {
   }
   FC_CHECK_HIP(hipEventRecord(m->ev_dw_in, c.s));
   FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in, 0));
-  if (c.s2nd) {
-    FC_CHECK_HIP(hipEventRecord(m->ev_dw_in2, c.s2nd));
-    FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in2, 0));
+  for (int k = 0; k < c.n_more; ++k) {
+    FC_CHECK_HIP(hipEventRecord(m->ev_dw_in2[k], m->mbs[k]));
+    FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in2[k], 0));
   }
   FC_TRY(fc_gemm_tn_grouped(st.dev + beg, (int)n, tiles, m->dws));
   st.flushed = all.size();
@@ -798,27 +813,31 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     Ctx c2 = c;
     c2.s = m->side;
     FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads));      // text tower (short) first: its dW chunks start early
-    if (microbatches(m, w.B) == 2 && c.defer) {
-      // image tower as two micro-batch chains, interleaved layer by layer; the full-batch weight gradients of a layer are
-      // queued once both chains have enqueued it, and flushed to the dW stream every few layers behind BOTH chains
-      const int b1 = w.B / 2;
+    const int nmb = c.defer ? microbatches(m, w.B) : 1;
+    if (nmb > 1) {
+      // image tower as micro-batch chains, interleaved layer by layer; the full-batch weight gradients of a layer are
+      // queued once every chain has enqueued it, and flushed to the dW stream every few layers behind ALL chains
       const size_t ow = (size_t)((w.feat_out || m->tw[0].task == FC_TASK_RTV) ? m->cfg.dim : m->tw[0].ncls);
-      Ws wa = slice_ws(m, w, 0, 0, b1, 0), wb = slice_ws(m, w, 0, b1, w.B - b1, 1);
-      Ctx ca = c, cb = c, cf_ = c;
-      ca.no_wgrad = cb.no_wgrad = true;
-      cb.s = m->mbs;
-      cf_.lnq = nullptr;          // (no kernels run through the full-batch context)
-      cf_.s2nd = m->mbs;
-      FC_TRY(tower_backward(ca, wa, 0, d_out_img, grads, PH_HEAD));
-      FC_TRY(tower_backward(cb, wb, 0, d_out_img + (size_t)b1 * ow, grads, PH_HEAD));
+      Ws wk[4];
+      Ctx ck[4];
+      const float* dk[4];
+      for (int k = 0; k < nmb; ++k) {
+        const int b0 = (int)((long)w.B * k / nmb), b1 = (int)((long)w.B * (k + 1) / nmb);
+        wk[k] = slice_ws(m, w, 0, b0, b1 - b0, k);
+        ck[k] = c;
+        ck[k].no_wgrad = true;
+        if (k > 0) ck[k].s = m->mbs[k - 1];
+        dk[k] = d_out_img + (size_t)b0 * ow;
+      }
+      Ctx cf_ = c;
+      cf_.n_more = nmb - 1;
+      for (int k = 0; k < nmb; ++k) FC_TRY(tower_backward(ck[k], wk[k], 0, dk[k], grads, PH_HEAD));
       for (int l = m->cfg.depth - 1; l >= 0; --l) {
-        FC_TRY(tower_backward(ca, wa, 0, d_out_img, grads, PH_LAYER, l));
-        FC_TRY(tower_backward(cb, wb, 0, d_out_img, grads, PH_LAYER, l));
+        for (int k = 0; k < nmb; ++k) FC_TRY(tower_backward(ck[k], wk[k], 0, dk[k], grads, PH_LAYER, l));
         FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_LAYER, l));
         if (dw_flush_here(l)) FC_TRY(flush_dw(cf_));
       }
-      FC_TRY(tower_backward(ca, wa, 0, d_out_img, grads, PH_EMBED));
-      FC_TRY(tower_backward(cb, wb, 0, d_out_img, grads, PH_EMBED));
+      for (int k = 0; k < nmb; ++k) FC_TRY(tower_backward(ck[k], wk[k], 0, dk[k], grads, PH_EMBED));
       FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_EMBED));
       FC_TRY(flush_dw(cf_));
     } else {
