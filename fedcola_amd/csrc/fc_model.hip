@@ -678,7 +678,8 @@ static int flush_dw(const Ctx& c) {
     FC_CHECK_HIP(hipEventRecord(m->ev_dw_in2[k], m->mbs[k]));
     FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in2[k], 0));
   }
-  FC_TRY(fc_gemm_tn_grouped(st.dev + beg, (int)n, tiles, m->dws));
+  static const bool ablate_dw = getenv("FC_ABLATE_DW") != nullptr;   // measurement aid: skip the weight-gradient GEMMs (wrong results)
+  if (!ablate_dw) FC_TRY(fc_gemm_tn_grouped(st.dev + beg, (int)n, tiles, m->dws));
   st.flushed = all.size();
   return 0;
 }
