@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--h2d", action="store_true", help="non-default: batches start in pinned host memory and reach the GPU through "
+                    "fedcola_amd.loaders.DevicePrefetcher (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--fedprox-mu", type=float, default=0.0, help="non-default workload: FedproxClient step (proximal term, row N3)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -183,7 +185,20 @@ def main():
         gflat = model.flat.detach().clone()
         pscr = torch.empty(L.fc_prox_scratch_bytes(model._handle.h), dtype=torch.uint8, device=dev)
 
+    feed = None
+    if a.h2d:
+        from fedcola_amd.loaders import DevicePrefetcher
+        himg, hids = img.cpu().pin_memory(), ids.cpu().pin_memory()      # what DataLoader(pin_memory=True) hands over
+
+        def host_batches():
+            while True:
+                yield himg, hids
+        feed = iter(DevicePrefetcher(host_batches(), dev, depth=2, stream=model.side_stream()))
+
     def step():
+        nonlocal img, ids
+        if feed is not None:
+            img, ids = next(feed)
         step_no[0] += 1
         args = (model._handle.h, P(model.flat), P(grads), P(m1), P(m2), P(model._wc_or_flat()), P(img), P(ids), None,
                 B, seq, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, step_no[0], P(lossbuf), P(ws), ws.numel(), sp)
@@ -239,7 +254,8 @@ def main():
                    vs_baseline=None, dtype=a.precision, data="synthetic",
                    config=dict(workload="Flickr30k FedCola, 1 img-txt client per GPU, mome_small_patch16 (ViT-S + 12x384 text tower), "
                                         f"B={B}, 224x224 RGB, {seq}-token captions, vocab 7732, AdamW lr 1e-4, drop-path 0"
-                                        + (f", FedProx mu={a.fedprox_mu}" if a.fedprox_mu > 0 else ""),
+                                        + (f", FedProx mu={a.fedprox_mu}" if a.fedprox_mu > 0 else "")
+                                        + (", batches from host memory through the device prefetcher" if a.h2d else ""),
                                global_batch=world * B, parallelism=f"{world} concurrent clients + RCCL FedAvg all-reduce"),
                    step_mfma_frac=round(pairs * PAIR_GFLOP / 1e3 / (world * PEAK_BF16_TFLOPS), 4), last_loss=round(loss, 4), enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
         if not a.no_roofline:

@@ -58,6 +58,7 @@ SIGNATURES = {
     "fc_ce_loss_fwd_bwd": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     "fc_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
     "fc_client_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _I, _P, _P, _Z, _P]),
+    "fc_model_side_stream": (C.c_void_p, [_P]),
     "fc_client_step_prox": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _I, _P, _P, _Z, _P, _P, _F, _P, _Z]),
     "fc_prox_scratch_bytes": (C.c_size_t, [_P]),
     "fc_prox_term": (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P, _Z, _P]),

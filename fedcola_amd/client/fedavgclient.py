@@ -85,7 +85,11 @@ class FedavgClient(BaseClient):
             num = 0
             lossbuf.zero_()
             broke = False
-            for batch in self.train_loader:
+            loader = self.train_loader
+            if dev.type == "cuda" and getattr(self.args, "prefetch", True):
+                from ..loaders.prefetch import DevicePrefetcher       # H2D of the next batches on a copy stream (N4)
+                loader = DevicePrefetcher(self.train_loader, dev, depth=2, stream=model.side_stream())
+            for batch in loader:
                 if num >= 2 and self.args.debug:                       # fedavgclient.py:73-75
                     mm.add_loss_sum(lossbuf[0].clone())
                     mm.aggregate(num * self.args.B, e + 1)

@@ -555,6 +555,10 @@ static int ensure_side(const fc_model* m) {
   }
   return 0;
 }
+extern "C" void* fc_model_side_stream(const fc_model_t* m) {
+  if (!m || ensure_side(m) != 0) return nullptr;
+  return (void*)m->side;
+}
 static int fork_side(const fc_model* m, hipStream_t s) {   // side (text tower) and micro-batch streams start after `s`
   FC_TRY(ensure_side(m));
   FC_CHECK_HIP(hipEventRecord(m->ev_fork, s));

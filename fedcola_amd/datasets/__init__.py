@@ -1,0 +1,2 @@
+"""On-disk dataset formats of the retrieval clients."""
+from .flickr30k import Flickr30kCap, fetch_flickr30k  # noqa: F401

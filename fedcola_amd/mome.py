@@ -290,6 +290,14 @@ class ModalityAgnosticTransformer(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.flat.device)
         return self._ws
 
+    def side_stream(self):
+        """The library's auxiliary stream (text tower) as a torch stream: where the next batch's H2D copy belongs
+        (fedcola_amd.loaders.DevicePrefetcher)."""
+        h = _lib.lib().fc_model_side_stream(self._handle.h)
+        if not h:
+            raise _lib.FedcolaHipError(_lib.lib().fc_last_error().decode())
+        return torch.cuda.ExternalStream(int(h), device=self.flat.device)
+
     def make_droppath(self, B: int, generator=None) -> Optional[torch.Tensor]:
         """timm DropPath multipliers [2, depth, 2, B] (0 or 1/keep), drawn on device; None when inactive (eval / rate 0)."""
         if not self.training or self.drop_path_rate <= 0.0:

@@ -1,7 +1,8 @@
-"""``FedproxServer`` (/root/reference/src/server/fedproxserver.py:9-11): FedAvg aggregation, FedProx clients."""
+"""``--algorithm fedprox`` resolves the server class by name (main.py:37): /root/reference/src/server/fedproxserver.py:9-11 is
+FedavgServer under another name -- same constructor, aggregation and evaluation; only the clients it builds differ
+(``fedproxclient.FedproxClient`` through the plugin lookup of ``_create_clients``)."""
 from .fedavgserver import FedavgServer
 
 
 class FedproxServer(FedavgServer):
-    def __init__(self, **kwargs):
-        super().__init__(**kwargs)
+    pass

@@ -57,6 +57,11 @@ int32_t fc_model_num_segments(const fc_model_t* m);
 int fc_model_segment(const fc_model_t* m, int32_t i, fc_segment* out);
 int fc_model_set_trainable(fc_model_t* m, int32_t seg, int32_t trainable);  /* fedavgserver.py:422-429 freeze */
 
+/* The library's auxiliary HIP stream (hipStream_t as void*) that carries the text tower.  It idles for most of a step, so the
+ * host->device copy of the NEXT batch belongs there (fedcola_amd/loaders/prefetch.py): the GPU runs at most four hardware
+ * queues well (caller, text, second image chain, weight gradients) and a fifth stream for copies costs more than it hides. */
+void* fc_model_side_stream(const fc_model_t* m);
+
 /* ---- sizes of caller-provided buffers */
 size_t fc_workspace_bytes(const fc_model_t* m, int32_t B, int32_t n_txt);   /* activations saved for backward + temporaries */
 size_t fc_compute_weights_bytes(const fc_model_t* m);                        /* 0 => pass the params buffer itself */

@@ -11,6 +11,7 @@ Outputs (tests/golden/):
     agg.json            FedavgServer._aggregate outputs over the scope / compensation matrix
     sampling.json       FedavgServer._sample_clients id lists
     init.json           default-init state_dict fingerprints under torch.manual_seed (factory order check)
+    split.json          simulate_split client -> index maps under np.random.seed (iid / unbalanced / caption sets / patho / diri)
     retrieval.json      COCOEvaluator.extract_features ordering, best ranks and recall scores on synthetic features
 
 Inputs and weights are NOT stored: they come from tests/synth.py's exact integer generator, so a fixture
@@ -285,6 +286,39 @@ def init_case():
     print("init ok")
 
 
+SPLIT_CASES = [
+    dict(name="iid", split_type="iid", dataset="CIFAR100", K=7, n=103, seed=3),
+    dict(name="unbalanced", split_type="unbalanced", dataset="CIFAR100", K=5, n=211, seed=4),
+    dict(name="flickr", split_type="unbalanced", dataset="Flickr30k", K=6, n=5 * 157, seed=5),
+    dict(name="coco_noniid_name", split_type="diri", dataset="Coco", K=4, n=5 * 90, seed=6),     # caption sets ignore the type
+    dict(name="patho", split_type="patho", dataset="CIFAR100", K=10, n=400, seed=7, mincls=2, num_classes=10),
+    dict(name="diri", split_type="diri", dataset="CIFAR100", K=5, n=600, seed=8, cncntrtn=0.5, num_classes=6),
+]
+
+
+def split_case():
+    """simulate_split (src/loaders/split.py) under np.random.seed: the client -> sample-index maps."""
+    import importlib
+    import numpy as np
+    sp = importlib.import_module("src.loaders.split")
+    recs = []
+    for c in SPLIT_CASES:
+        class DS:
+            def __init__(self, n, ncls):
+                self.targets = [(i * 7 + i // 3) % ncls for i in range(n)]
+
+            def __len__(self):
+                return len(self.targets)
+        a = RefArgs(**{k: v for k, v in c.items() if k not in ("name", "n", "seed")})
+        np.random.seed(c["seed"])
+        m = sp.simulate_split(a, DS(c["n"], c.get("num_classes", 10)))
+        tail = float(np.random.uniform())                       # the RNG stream position after the call is part of the contract
+        recs.append(dict(cfg=c, map={str(k): [int(x) for x in v] for k, v in m.items()}, next_uniform=tail))
+    with open(os.path.join(HERE, "split.json"), "w") as f:
+        json.dump(recs, f)
+    print("split ok", [(r["cfg"]["name"], [len(v) for v in r["map"].values()]) for r in recs])
+
+
 def retrieval_case():
     """COCOEvaluator (src/metrics/eval_coco.py) on synthetic features: collected ordering, best ranks, scores."""
     import importlib
@@ -326,6 +360,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "retrieval":
         retrieval_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "split":
+        split_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "prox":
         update_prox_case()
         sys.exit(0)
@@ -337,3 +374,4 @@ if __name__ == "__main__":
     sampling_case()
     init_case()
     retrieval_case()
+    split_case()

@@ -1,0 +1,103 @@
+"""N4 (input side of the path): client splits bit-exact against the reference's numpy RNG stream (tests/golden/split.json),
+the Flickr30k on-disk format, and the device prefetcher's ordering contract (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from refstub import RefArgs, reference_available
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SPLITS = json.load(open(os.path.join(HERE, "golden", "split.json")))
+
+
+class _DS:
+    def __init__(self, n, ncls):
+        self.targets = [(i * 7 + i // 3) % ncls for i in range(n)]
+
+    def __len__(self):
+        return len(self.targets)
+
+
+@pytest.mark.parametrize("rec", SPLITS, ids=[r["cfg"]["name"] for r in SPLITS])
+def test_simulate_split_bit_exact(rec):
+    from fedcola_amd.loaders.split import simulate_split
+    c = rec["cfg"]
+    a = RefArgs(**{k: v for k, v in c.items() if k not in ("name", "n", "seed")})
+    np.random.seed(c["seed"])
+    m = simulate_split(a, _DS(c["n"], c.get("num_classes", 10)))
+    assert {str(k): [int(x) for x in v] for k, v in m.items()} == rec["map"]           # index work: bit-exact
+    assert float(np.random.uniform()) == rec["next_uniform"]                             # same number of RNG draws consumed
+    if c["dataset"] in ("Flickr30k", "Coco"):
+        for v in m.values():                                                             # whole images: 5 consecutive captions
+            v = np.asarray(v)
+            assert len(v) % 5 == 0 and np.all(v[::5] % 5 == 0) and np.all(np.diff(v.reshape(-1, 5), axis=1) == 1)
+
+
+def test_split_errors():
+    from fedcola_amd.loaders.split import simulate_split
+    with pytest.raises(AssertionError):
+        simulate_split(RefArgs(split_type="patho", dataset="CIFAR100", K=4, mincls=1, num_classes=10), _DS(40, 10))
+    with pytest.raises(Exception):
+        simulate_split(RefArgs(split_type="patho", dataset="CIFAR100", K=2, mincls=2, num_classes=10), _DS(40, 10))
+
+
+def _make_flickr(root, n_images=3):
+    from PIL import Image
+    os.makedirs(os.path.join(root, "flickr30k_images"), exist_ok=True)
+    rows = ["image_name| comment_number| comment"]
+    for i in range(n_images):
+        name = f"{1000 + i}.jpg"
+        Image.fromarray((np.arange(8 * 8 * 3, dtype=np.uint8).reshape(8, 8, 3) + 13 * i)).save(os.path.join(root, "flickr30k_images", name.replace(".jpg", ".png")))
+        os.replace(os.path.join(root, "flickr30k_images", name.replace(".jpg", ".png")), os.path.join(root, "flickr30k_images", name))
+        for j in range(5):
+            rows.append(f"{name}| {j}| A caption number {j} , with a comma and \"quotes\" for image {i} .")
+    for split in ("train", "test", "train_all"):
+        with open(os.path.join(root, f"{split}.csv"), "w") as f:
+            f.write("\n".join(rows if split != "test" else rows[:6]) + "\n")
+
+
+def _tok(text, padding=None, truncation=None, max_length=8, return_tensors=None):
+    ids = [min(len(w), 29) for w in text.split()][:max_length]
+    return {"input_ids": torch.tensor([ids + [0] * (max_length - len(ids))])}
+
+
+def test_flickr30k_format(tmp_path):
+    from fedcola_amd.datasets.flickr30k import Flickr30kCap, fetch_flickr30k
+    root = str(tmp_path)
+    _make_flickr(root)
+    to_t = lambda im: torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1)
+    ds = Flickr30kCap(root, split="train", transform=to_t, tokenizer=_tok, max_length=8)
+    assert len(ds) == 15 and ds.n_images == 3 and ds.iid_to_cls == {}
+    img, cap, iid, aid, idx = ds[7]
+    assert (iid, aid, idx) == (1, 7, 7) and tuple(img.shape) == (3, 8, 8) and cap.shape == (8,)
+    assert ds.captions[7].strip().startswith("A caption number 2 , with a comma")
+    a = RefArgs(seq_len=8, flickr_train_all=True)
+    tr, te, a2 = fetch_flickr30k(a, root, (to_t, to_t), _tok)
+    assert len(tr) == 15 and len(te) == 5 and tr.name == "Flickr30k" and tr.task == "img+txt" and a2.in_channels == 3 and a2.num_classes is None
+    if reference_available():          # same parse as the reference's class, sample by sample
+        import refstub
+        refstub.load_reference()
+        import importlib
+        ref = importlib.import_module("src.datasets.flickr30k")
+        rd = ref.Flickr30kCap(root, split="train", transform=to_t, tokenizer=_tok, max_length=8)
+        assert rd.captions == ds.captions and list(rd.images) == list(ds.images) and rd.n_images == ds.n_images
+        for i in (0, 4, 5, 14):
+            x, y = rd[i], ds[i]
+            assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and x[2:] == y[2:]
+
+
+@pytest.mark.gpu
+def test_device_prefetcher_order_and_values():
+    from fedcola_amd.loaders.prefetch import DevicePrefetcher
+    batches = [(torch.full((4, 3, 16, 16), float(i)), torch.arange(8).repeat(4, 1) + i, i) for i in range(7)]
+    for depth in (1, 2, 3):
+        got = list(DevicePrefetcher(batches, "cuda", depth=depth))
+        assert len(got) == 7
+        for i, (x, y, k) in enumerate(got):
+            assert x.is_cuda and y.is_cuda and k == i
+            assert float(x.mean()) == float(i) and int(y[0, 0]) == i
+    with pytest.raises(RuntimeError):
+        list(DevicePrefetcher(batches, "cpu"))
