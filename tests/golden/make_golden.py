@@ -11,6 +11,7 @@ Outputs (tests/golden/):
     agg.json            FedavgServer._aggregate outputs over the scope / compensation matrix
     sampling.json       FedavgServer._sample_clients id lists
     init.json           default-init state_dict fingerprints under torch.manual_seed (factory order check)
+    cream.json          CreamflClient.update() per modality and the server half of CreamflServer.update() on toy models
     split.json          simulate_split client -> index maps under np.random.seed (iid / unbalanced / caption sets / patho / diri)
     retrieval.json      COCOEvaluator.extract_features ordering, best ranks and recall scores on synthetic features
 
@@ -286,6 +287,75 @@ def init_case():
     print("init ok")
 
 
+def cream_case():
+    """CreamFL (src/client/creamflclient.py, src/server/creamflserver.py): CreamflClient.update() per modality (local epoch +
+    public-set contrastive distillation with clip_grad_norm 2) and CreamflServer.update()'s server half (contrastive feature
+    aggregation, zero-init weighted aggregate, KD distillation) on toy models."""
+    import types
+    import cream_util as CU
+    from synth import det_state_dict as dsd
+
+    def mk_model(kind):
+        m = ref.mome.ModalityAgnosticTransformer(**CU.MK[kind])
+        m.sync_shared_weights()
+        m.load_state_dict(dsd({k: tuple(v.shape) for k, v in m.state_dict().items()}, base_seed=CU.BASE_SEED[kind]), strict=True)
+        return m
+    gi, gt = CU.global_features()
+    pub = CU.PubSet()
+    dindex = [pub.index[i] for i in range(len(pub))]
+    rec = dict(clients={}, server={}, shapes={k: {n: list(v.shape) for n, v in mk_model(k).state_dict().items()} for k in CU.MK})
+    clients = {}
+    for cid, (kind, ds, task, crit, dsname) in enumerate([("img", CU.Cls("img"), "cls", "CrossEntropyLoss", "CIFAR100"),
+                                                          ("txt", CU.Cls("txt", classes=4), "cls", "CrossEntropyLoss", "AG_NEWS"),
+                                                          ("mm", CU.Pairs(), "rtv", "ContrastiveLoss", "Flickr30k")]):
+        args = RefArgs(**CU.CREAM_ARGS)
+        modality = {"img": "img", "txt": "txt", "mm": "img+txt"}[kind]
+        cl = ref.creamflclient.CreamflClient(args=args, training_set=ds, test_set=ds, task=task, modality=modality,
+                                             eval_metrics=["acc1"] if task == "cls" else [], criterion=crit)
+        cl.id, cl.dataset, cl.device = cid, dsname, "cpu"
+        cl.pub_dataset = pub
+        cl.global_img_feature, cl.global_txt_feature, cl.distill_index = gi.clone(), gt.clone(), list(dindex)
+        cl.download({dsname: mk_model(kind)})
+        res = cl.update()
+        r = dict(results={str(k): v for k, v in res.items()},
+                 after={k: pack(v, False) for k, v in cl.model.state_dict().items() if v.dtype.is_floating_point})
+        if kind != "mm":
+            cl.update_pub_feature()
+            r["pub_features"] = pack(cl.pub_features, True)
+            r["distill_index"] = [int(x) for x in cl.distill_index]
+        rec["clients"][kind] = r
+        clients[cid] = cl
+        print("cream client", kind, res)
+    # ---- server half: the REAL CreamflServer.update() body on a shell (client update / sampling stubbed out)
+    srv = object.__new__(ref.creamflserver.CreamflServer)
+    srv._round, srv._clients = 1, [clients[0], clients[1], clients[2]]
+    srv.args = RefArgs(datasets=["CIFAR100", "AG_NEWS", "Flickr30k"], modalities=["img", "txt", "img+txt"], lr_decay=0.99, lr_decay_step=1,
+                       **CU.CREAM_ARGS)
+    srv.global_models = {"CIFAR100": mk_model("img"), "AG_NEWS": mk_model("txt"), "Flickr30k": mk_model("mm")}
+    srv._init_param_scope("none", "dataset")
+    srv.device, srv.curr_lr = "cpu", 1e-3
+    srv.global_img_feature, srv.global_txt_feature, srv.distill_index = gi.clone(), gt.clone(), list(dindex)
+    srv.pub_loader = list(torch.utils.data.DataLoader(pub, batch_size=4, shuffle=False))
+    clients[0].pub_features = CU.client_pub_features(81)
+    clients[1].pub_features = CU.client_pub_features(82)
+    extra_img = types.SimpleNamespace(id=3, modality="img", dataset="CIFAR100", task="cls", pub_features=CU.client_pub_features(83),
+                                      upload=lambda: clients[0].upload(), training_set=list(range(9)))
+    srv._clients.append(extra_img)
+    sizes = {0: 6, 1: 6, 2: 6, 3: 9}
+    srv._generate_public_logit = lambda: None
+    srv._sample_clients = lambda: [0, 1, 2, 3]
+    srv._request = lambda *a, **k: dict(sizes)
+    srv._empty_client_models = lambda: None
+    ids = srv.update()
+    rec["server"] = dict(ids=ids, sizes={str(k): v for k, v in sizes.items()}, img_vec=pack(srv.img_vec, True), txt_vec=pack(srv.txt_vec, True),
+                         curr_lr=srv.curr_lr,
+                         after={ds: {k: pack(v, False) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+                                for ds, m in srv.global_models.items()})
+    with open(os.path.join(HERE, "cream.json"), "w") as f:
+        json.dump(rec, f)
+    print("cream ok")
+
+
 SPLIT_CASES = [
     dict(name="iid", split_type="iid", dataset="CIFAR100", K=7, n=103, seed=3),
     dict(name="unbalanced", split_type="unbalanced", dataset="CIFAR100", K=5, n=211, seed=4),
@@ -360,6 +430,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "retrieval":
         retrieval_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cream":
+        cream_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "split":
         split_case()
         sys.exit(0)
@@ -375,3 +448,4 @@ if __name__ == "__main__":
     init_case()
     retrieval_case()
     split_case()
+    cream_case()

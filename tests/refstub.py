@@ -96,8 +96,10 @@ def load_reference():
     import src.client.fedavgclient as fedavgclient
     import src.server.fedavgserver as fedavgserver
     import src.client.fedproxclient as fedproxclient
+    import src.client.creamflclient as creamflclient
+    import src.server.creamflserver as creamflserver
 
-    ns = types.SimpleNamespace(mome=mome, fedavgclient=fedavgclient, fedavgserver=fedavgserver, fedproxclient=fedproxclient,
+    ns = types.SimpleNamespace(mome=mome, fedavgclient=fedavgclient, fedavgserver=fedavgserver, fedproxclient=fedproxclient, creamflclient=creamflclient, creamflserver=creamflserver,
                                create_model=create_model, registry=registry, DropPath=DropPath)
     _loaded["ns"] = ns
     return ns
