@@ -59,6 +59,16 @@ SIGNATURES = {
     "fc_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
     "fc_client_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _I, _P, _P, _Z, _P]),
     "fc_model_side_stream": (C.c_void_p, [_P]),
+    "fc_gather_rows": (C.c_int, [_P, _P, _I, _I, _P, _P]),
+    "fc_cream_moon_loss": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P]),
+    "fc_cream_inter_scratch_floats": (C.c_size_t, [_I, _I]),
+    "fc_cream_inter_loss": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P, _Z, _P, _P, _I, _P]),
+    "fc_clip_scratch_bytes": (C.c_size_t, [_P]),
+    "fc_clip_grad_norm": (C.c_int, [_P, _P, _F, _P, _Z, _P, _P]),
+    "fc_adamw_step_segs": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P, _I, _P, _P]),
+    "fc_mse_loss_fwd_bwd": (C.c_int, [_P, _P, _L, _F, _I, _P, _P, _P]),
+    "fc_cream_logprob_diag": (C.c_int, [_P, _P, _I, _I, _P, _P]),
+    "fc_cream_combine": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "fc_client_step_prox": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _I, _P, _P, _Z, _P, _P, _F, _P, _Z]),
     "fc_prox_scratch_bytes": (C.c_size_t, [_P]),
     "fc_prox_term": (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P, _Z, _P]),

@@ -131,8 +131,10 @@ class BlendPlan:
     weights: torch.Tensor            # float32 [nseg, m+1]  (w_g, w_1..w_m)
 
 
-def build_plan(global_model, ids: Sequence[int], coefficients, client_segments: Mapping[int, Mapping[str, dict]]) -> BlendPlan:
-    """client_segments[i][key] -> {'offset':..} of the keys client i uploads (aux / scale keys already dropped)."""
+def build_plan(global_model, ids: Sequence[int], coefficients, client_segments: Mapping[int, Mapping[str, dict]],
+               zero_init: bool = False) -> BlendPlan:
+    """client_segments[i][key] -> {'offset':..} of the keys client i uploads (aux / scale keys already dropped).
+    zero_init: CreamflServer._aggregate (creamflserver.py:257-288) -- a plain weighted sum into zeros: w_g = 0, w_j = c_j."""
     keys = list(coefficients.keys())
     m = len(ids)
     seg_off = torch.empty(len(keys), dtype=torch.int64)
@@ -144,7 +146,7 @@ def build_plan(global_model, ids: Sequence[int], coefficients, client_segments: 
         seg_off[s] = gseg[k]["offset"]
         seg_len[s] = gseg[k]["numel"]
         part = [(j, i) for j, i in enumerate(ids) if k in client_segments[i] and coefficients[k][i] != 0]
-        wg, w = effective_weights([coefficients[k][i] for _, i in part])
+        wg, w = (0.0, [coefficients[k][i] for _, i in part]) if zero_init else effective_weights([coefficients[k][i] for _, i in part])
         weights[s, 0] = wg
         for (j, i), wj in zip(part, w):
             weights[s, 1 + j] = wj

@@ -52,6 +52,22 @@ class FedavgClient(BaseClient):
         return torch.utils.data.DataLoader(dataset=dataset, batch_size=self.args.B, shuffle=shuffle)
 
     # ------------------------------------------------------------------ the hot loop (fedavgclient.py:55-116)
+    # ---- hooks for subclasses that interleave other optimizer steps with the fused ones (creamflclient.py)
+    def _before_update(self, st):
+        pass
+
+    def _after_epoch(self, e, st, step):
+        return step
+
+    def _fused_step_ok(self, st):
+        return True
+
+    def _count_step(self, st, skipped):
+        pass
+
+    def _segmented_step(self, st, *a):
+        raise NotImplementedError
+
     def _prox(self):
         """(global flat copy, mu) for a proximal term, or None -- overridden by FedproxClient."""
         return None
@@ -81,6 +97,9 @@ class FedavgClient(BaseClient):
         if prox is not None:
             prox_scratch = torch.empty(L.fc_prox_scratch_bytes(model._handle.h), dtype=torch.uint8, device=dev)
         step = 0
+        # optimizer state of this round, shared with subclasses' extra steps (CreamFL's public-set distillation)
+        st = dict(grads=grads, exp_avg=exp_avg, exp_avg_sq=exp_avg_sq, lr=lr, betas=betas, eps=eps, wd=wd, dev=dev, steps_done=0)
+        self._before_update(st)
         for e in range(self.args.E):
             num = 0
             lossbuf.zero_()
@@ -114,6 +133,18 @@ class FedavgClient(BaseClient):
                 ws = model.workspace(B, n_txt)
                 dp = model.make_droppath(B)
                 step += 1
+                if not self._fused_step_ok(st):
+                    self._segmented_step(st, img, ids, labels, B, n_txt, dp, ws, lossbuf)
+                    model._wc_version = model.flat._version
+                    if mm.metric_funcs:
+                        i = 0 if self.modality == "img" else 1
+                        logits = torch.empty(B, model.num_classes[i], device=dev)
+                        check(L.fc_copy_outputs(model._handle.h, ptr(ws), ws.numel(), ptr(logits) if i == 0 else None,
+                                                ptr(logits) if i == 1 else None, _lib.stream_ptr()))
+                        for module in mm.metric_funcs.values():
+                            module.collect(logits, labels)
+                    num += 1
+                    continue
                 step_args = (model._handle.h, ptr(model.flat), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(model._wc_or_flat()),
                              ptr(img), ptr(ids), ptr(labels), B, n_txt, ptr(dp), lr, float(betas[0]), float(betas[1]), eps, wd,
                              step, ptr(lossbuf), ptr(ws), ws.numel(), _lib.stream_ptr())
@@ -122,6 +153,8 @@ class FedavgClient(BaseClient):
                 else:                                                   # fedproxclient.py:64-67 inside the same fused step
                     check(L.fc_client_step_prox(*step_args, ptr(prox[0]), float(prox[1]), ptr(prox_scratch), prox_scratch.numel()))
                 model._wc_version = model.flat._version          # fc_client_step refreshed the compute weights itself
+                st["steps_done"] = step
+                self._count_step(st, None)
                 if mm.metric_funcs:                                    # acc1 etc. for uni-modal clients
                     i = 0 if self.modality == "img" else 1
                     logits = torch.empty(B, model.num_classes[i], device=dev)
@@ -135,6 +168,7 @@ class FedavgClient(BaseClient):
                 mm.aggregate(len(self.training_set), e + 1)
                 res = mm.results[e + 1]
                 logger.info(f'[Client {self.id}] loss: {res["loss"]}')
+            step = self._after_epoch(e, st, step)
         # the reference moves the model back to the CPU here (fedavgclient.py:114); weights stay resident in HBM instead
         return mm.results
 

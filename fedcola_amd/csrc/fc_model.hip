@@ -48,6 +48,8 @@ struct fc_model {
   mutable std::vector<FcLnReduce> ln_host;        // same for the grouped LayerNorm-gradient reduction
   mutable std::vector<char> prox_host;            // same for the FedProx chunk table
   mutable const void* prox_dev = nullptr;
+  mutable std::vector<char> clip_host;            // ... and for the gradient-clipping chunk table
+  mutable const void* clip_dev = nullptr;
   mutable const void* ln_dev = nullptr;
   // the two towers are independent until the loss: the text tower runs on a side stream, forked/joined with events
   mutable hipStream_t side = nullptr;
@@ -953,14 +955,73 @@ extern "C" int fc_prox_term(const fc_model_t* m, const float* params, const floa
   std::vector<char> img(b0 + b1, 0);
   memcpy(img.data(), ch.data(), ch.size() * sizeof(FcProxChunk));
   memcpy(img.data() + b0, first.data(), first.size() * sizeof(int32_t));
-  if (!(m->prox_dev == scratch && m->prox_host == img)) {     // tables are uploaded once per (scratch, trainable set)
-    FC_CHECK_HIP(hipStreamSynchronize(s));
+  // The tables are re-sent on every call (~50 KB): the scratch is the caller's, and a freed-and-reallocated buffer can come back at
+  // the same address with other contents, so "same pointer" proves nothing about what it holds.
+  if (m->prox_host != img) {
+    FC_CHECK_HIP(hipStreamSynchronize(s));        // an in-flight copy may still read the old host image
     m->prox_host = img;
-    m->prox_dev = scratch;
-    FC_CHECK_HIP(hipMemcpyAsync(base, m->prox_host.data(), m->prox_host.size(), hipMemcpyHostToDevice, s));
   }
+  m->prox_dev = scratch;
+  FC_CHECK_HIP(hipMemcpyAsync(base, m->prox_host.data(), m->prox_host.size(), hipMemcpyHostToDevice, s));
   return fc_prox_term_impl(params, global_params, (const FcProxChunk*)base, (int)ch.size(), (const int32_t*)(base + b0), (int)first.size() - 1,
                            (float*)(base + b0 + b1), (float*)(base + b0 + b1 + b2), mu, B, grads, lossbuf, s);
+}
+
+// ---- torch.nn.utils.clip_grad_norm_ over the trainable parameter tensors (creamflclient.py:232, creamflserver.py:334)
+int fc_clip_impl(float* grads, const FcProxChunk* chunks, int nchunks, float* partial, float* coef_norm, float max_norm, hipStream_t s);
+extern "C" size_t fc_clip_scratch_bytes(const fc_model_t* m) {
+  std::vector<FcProxChunk> ch;
+  std::vector<int32_t> first;
+  prox_tables(m, ch, first);
+  return align16(ch.size() * sizeof(FcProxChunk)) + align16(ch.size() * sizeof(float)) + 16;
+}
+extern "C" int fc_clip_grad_norm(const fc_model_t* m, float* grads, float max_norm, void* scratch, size_t scratch_bytes, float* total_norm_out,
+                                 void* stream) {
+  FC_REQUIRE(grads && scratch, "fc_clip_grad_norm: null buffer");
+  FC_REQUIRE(scratch_bytes >= fc_clip_scratch_bytes(m), "fc_clip_grad_norm: scratch too small");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<FcProxChunk> ch;
+  std::vector<int32_t> first;
+  prox_tables(m, ch, first);
+  const size_t b0 = align16(ch.size() * sizeof(FcProxChunk)), b1 = align16(ch.size() * sizeof(float));
+  std::vector<char> img(b0, 0);
+  memcpy(img.data(), ch.data(), ch.size() * sizeof(FcProxChunk));
+  char* base = (char*)scratch;
+  if (m->clip_host != img) {                      // (see fc_prox_term: the table is re-sent on every call)
+    FC_CHECK_HIP(hipStreamSynchronize(s));
+    m->clip_host = img;
+  }
+  m->clip_dev = scratch;
+  FC_CHECK_HIP(hipMemcpyAsync(base, m->clip_host.data(), m->clip_host.size(), hipMemcpyHostToDevice, s));
+  float* coef_norm = (float*)(base + b0 + b1);
+  FC_TRY(fc_clip_impl(grads, (const FcProxChunk*)base, (int)ch.size(), (float*)(base + b0), coef_norm, max_norm, s));
+  if (total_norm_out) FC_CHECK_HIP(hipMemcpyAsync(total_norm_out, coef_norm + 1, sizeof(float), hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// ---- torch.optim.AdamW with per-parameter step counts: seg_steps[i] is the 1-based step of segment i in THIS call, 0 = the
+// parameter has no gradient and is skipped (torch skips parameters whose .grad is None and does not advance their step)
+extern "C" int fc_adamw_step_segs(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, const int32_t* seg_steps, int32_t n_segments, void* wc, void* stream) {
+  FC_REQUIRE(params && grads && exp_avg && exp_avg_sq && seg_steps, "fc_adamw_step_segs: null buffer");
+  FC_REQUIRE(n_segments == (int32_t)m->segs.size(), "fc_adamw_step_segs: %d step entries for %zu segments", n_segments, m->segs.size());
+  bool has_aux = false;
+  for (const fc_segment& sg : m->segs)
+    if (strstr(sg.name, "aux_weight")) has_aux = true;
+  bf16_t* shadow = (wc && m->need_wc && m->dt == FC_BF16 && !has_aux) ? (bf16_t*)wc : nullptr;
+  const size_t n = m->segs.size();
+  size_t i = 0;
+  while (i < n) {
+    if (!m->segs[i].trainable || seg_steps[i] <= 0) { ++i; continue; }
+    size_t j = i;
+    while (j + 1 < n && m->segs[j + 1].trainable && seg_steps[j + 1] == seg_steps[i]) ++j;
+    const int64_t beg = m->segs[i].offset, end = (j + 1 < n) ? m->segs[j + 1].offset : m->total;
+    FC_TRY(fc_adamw(params + beg, grads + beg, exp_avg + beg, exp_avg_sq + beg, (size_t)(end - beg), lr, beta1, beta2, eps, weight_decay,
+                    seg_steps[i], shadow ? shadow + beg : nullptr, 0, (hipStream_t)stream));
+    i = j + 1;
+  }
+  if (wc && m->need_wc && !shadow) FC_TRY(fc_prepare_weights(m, params, wc, stream));
+  return 0;
 }
 
 static int client_step_impl(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,

@@ -178,7 +178,9 @@ class FedavgServer(BaseServer):
                     self._freeze_shared_params(client)
                 elif self.round > (self.args.freeze_rounds + self.args.warmup_rounds):
                     self._unfreeze_params(client)
+            self._before_client_update(client)
             results[client.id] = client.update()
+            self._after_client_update(client)
             sizes[client.id] = len(client.training_set)
             if not retain_model:
                 client.model = None
@@ -191,6 +193,12 @@ class FedavgServer(BaseServer):
                 results.update(r)
         self.results[self.round]["clients_updated"] = {str(k): v for k, v in results.items()}
         return sizes
+
+    def _before_client_update(self, client):
+        """Hook of the update fan-out (no-op here; CreamFL hands the global public features to the client)."""
+
+    def _after_client_update(self, client):
+        """Hook of the update fan-out (no-op here; CreamFL refreshes the client's public features)."""
 
     # ------------------------------------------------------------------ aggregation hook
     def _client_upload_segments(self, client):

@@ -119,6 +119,36 @@ int fc_client_step_prox(const fc_model_t* m, float* params, float* grads, float*
                         float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
                         void* stream, const float* global_params, float mu, void* prox_scratch, size_t prox_scratch_bytes);
 
+/* ---- CreamFL (src/client/creamflclient.py, src/server/creamflserver.py).  The model work of its
+ * distillation steps is fc_forward(feat_out) / fc_backward; these are the pieces around it.  Losses accumulate into lossbuf like
+ * the criteria above ([1] += weight*L, [0] += weight*L*B) and write (accumulate = 0) or add (1) weight*dL/df into df. */
+/* out[b] = table[idx[b]]: target features global_feature[d_idx] (creamflclient.py:160,169,203-204) */
+int fc_gather_rows(const float* table, const int64_t* idx, int32_t B, int32_t D, float* out, void* stream);
+/* logits = [f.target, f.old] / 0.5, label 0, cross-entropy summed over the B rows / rows_norm (creamflclient.py:175-186; the img+txt
+ * client stacks both modalities' rows into one CE, :207-217: call twice with rows_norm = 2B) */
+int fc_cream_moon_loss(const float* f, const float* target, const float* old_f, int32_t B, int32_t D, int32_t rows_norm, float weight,
+                       float* lossbuf, float* df, int32_t accumulate, void* stream);
+/* CE(f @ G^T / 0.5, labels), mean over B (creamflclient.py:165/173 + 181-182, :219-224).  G: [P, D]; scratch: fc_cream_inter_scratch_floats */
+size_t fc_cream_inter_scratch_floats(int32_t B, int32_t P);
+int fc_cream_inter_loss(const float* f, const float* G, const int64_t* labels, int32_t B, int32_t P, int32_t D, float weight, float* scratch,
+                        size_t scratch_floats, float* lossbuf, float* df, int32_t accumulate, void* stream);
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) over the trainable segments (creamflclient.py:232, creamflserver.py:334):
+ * grads *= min(1, max_norm / (||grads||_2 + 1e-6)); total_norm_out (device float, may be NULL) receives the norm */
+size_t fc_clip_scratch_bytes(const fc_model_t* m);
+int fc_clip_grad_norm(const fc_model_t* m, float* grads, float max_norm, void* scratch, size_t scratch_bytes, float* total_norm_out, void* stream);
+/* torch.optim.AdamW.step with torch's per-parameter bookkeeping: seg_steps (HOST int32[n_segments]) holds each segment's 1-based step
+ * for this call; 0 = no gradient this step -> skipped, its step count does not advance (a classification head during feature
+ * distillation).  wc (may be NULL): compute weights to refresh. */
+int fc_adamw_step_segs(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, const int32_t* seg_steps, int32_t n_segments, void* wc, void* stream);
+/* weight * nn.MSELoss()(out, target) over n elements (creamflserver.py:311-321) */
+int fc_mse_loss_fwd_bwd(const float* out, const float* target, int64_t n, float weight, int32_t B, float* lossbuf, float* dout, void* stream);
+/* server-side public-feature aggregation (creamflserver.py:373-405): w[i] = V_i.G_i - log sum_j exp(V_i.G_j) for one client's
+ * features V [P, D] against the global features G [P, D] of the other modality; then out[i] = sum_c softmax_c(w[c][i]) * V_c[i]
+ * (vecs_dev: device array of C device pointers; w: [C, P]) */
+int fc_cream_logprob_diag(const float* V, const float* G, int32_t P, int32_t D, float* w, void* stream);
+int fc_cream_combine(const float* const* vecs_dev, const float* w, int32_t C, int32_t P, int32_t D, float* out, void* stream);
+
 /* ---- FedavgServer._aggregate blend (fedavgserver.py:656-664) in closed form, per state_dict key (segment):
  * out[seg_offset[s] + i] = w[s][0]*global[seg_offset[s] + i] + sum_j w[s][1+j] * client_bases[j][src_offset[s][j] + i].
  * Clients of other datasets hold the key at another offset of their own flat buffer (src_offset, < 0: key absent).
