@@ -56,7 +56,7 @@ struct fc_model {
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // weight gradients are launched in chunks (every few layers) on their own stream, under the rest of the backward
   mutable hipStream_t dws = nullptr;
-  mutable hipEvent_t ev_dw_in = nullptr, ev_dw_in2[3] = {nullptr, nullptr, nullptr}, ev_dw_out = nullptr;
+  mutable hipEvent_t ev_dw_in = nullptr, ev_dw_in2[3] = {nullptr, nullptr, nullptr}, ev_dw_out = nullptr, ev_dw_prev = nullptr;
   // second micro-batch of the image tower
   mutable hipStream_t mbs[3] = {nullptr, nullptr, nullptr};      // micro-batch chains 1..3 (chain 0 runs on the caller's stream)
   mutable hipEvent_t ev_mb_join[3] = {nullptr, nullptr, nullptr};
@@ -69,6 +69,7 @@ struct fc_model {
       if (ev_mb_join[k]) (void)hipEventDestroy(ev_mb_join[k]);
     }
     if (ev_dw_out) (void)hipEventDestroy(ev_dw_out);
+    if (ev_dw_prev) (void)hipEventDestroy(ev_dw_prev);
     if (side) (void)hipStreamDestroy(side);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -549,6 +550,7 @@ static int ensure_side(const fc_model* m) {
       FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_mb_join[k], hipEventDisableTiming));
     }
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_out, hipEventDisableTiming));
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_prev, hipEventDisableTiming));
   }
   if (!m->side) {
     FC_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
@@ -800,8 +802,15 @@ static int tower_reparam_grads(const Ctx& c, int i, float* grads) {
   return 0;
 }
 
+// The LAST weight-gradient chunk (layers 0..1 of the image tower + the patch embedding) starts when the whole backward is done and
+// nothing is left to overlap it with -- except the optimizer: fc_client_step steps every parameter that does not depend on that
+// chunk first and waits for the chunk only before stepping the rest.
+struct LateDw {
+  bool pending = false;
+  std::vector<char> late_seg;     // per segment: its gradient is written by the last chunk
+};
 static int backward_impl(const fc_model* m, const float* params, const void* wc, const float* d_out_img, const float* d_out_txt, float* grads,
-                         Ws& w, hipStream_t s) {
+                         Ws& w, hipStream_t s, LateDw* late = nullptr) {
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
   std::vector<FcTnProblem> probs;
   std::vector<FcLnReduce> lnq;
@@ -846,6 +855,17 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
       }
       for (int k = 0; k < nmb; ++k) FC_TRY(tower_backward(ck[k], wk[k], 0, dk[k], grads, PH_EMBED));
       FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_EMBED));
+      if (late && dwst.flushed > 0 && dwst.flushed < probs.size()) {
+        FC_CHECK_HIP(hipEventRecord(m->ev_dw_prev, m->dws));      // every chunk but the last
+        late->late_seg.assign(m->segs.size(), 0);
+        for (size_t q = dwst.flushed; q < probs.size(); ++q) {
+          const int64_t offs[2] = {(int64_t)(probs[q].C - grads), probs[q].bias_grad ? (int64_t)(probs[q].bias_grad - grads) : -1};
+          for (int64_t off : offs)
+            for (size_t k = 0; off >= 0 && k < m->segs.size(); ++k)
+              if (m->segs[k].offset == off) late->late_seg[k] = 1;
+        }
+        late->pending = true;
+      }
       FC_TRY(flush_dw(cf_));
     } else {
       FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
@@ -869,7 +889,8 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
   }
   if (!probs.empty()) {   // every chunk was launched by flush_dw; the main stream continues after the last one
     FC_CHECK_HIP(hipEventRecord(m->ev_dw_out, m->dws));
-    FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
+    if (late && late->pending) FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_prev, 0));   // ... the caller waits for ev_dw_out itself
+    else FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
   }
   if (m->tw[0].present && d_out_img) FC_TRY(tower_reparam_grads(c, 0, grads));
   if (m->tw[1].present && d_out_txt) FC_TRY(tower_reparam_grads(c, 1, grads));
@@ -896,13 +917,15 @@ extern "C" int fc_ce_loss_fwd_bwd(const float* logits, const int64_t* y, int32_t
 }
 
 static int adamw_ranges(const fc_model* m, float* p, float* g, float* mm, float* vv, float lr, float b1, float b2, float eps, float wd, int step,
-                        hipStream_t s, bf16_t* shadow = nullptr) {
-  // contiguous runs of trainable segments (padding included) -> one launch each; frozen segments are skipped like torch
+                        hipStream_t s, bf16_t* shadow = nullptr, const std::vector<char>* late_seg = nullptr, int want_late = 0) {
+  // contiguous runs of trainable segments (padding included) -> one launch each; frozen segments are skipped like torch.
+  // late_seg / want_late: only the segments whose flag equals want_late (fc_client_step's two optimizer phases)
+  auto take = [&](size_t k) { return m->segs[k].trainable && (!late_seg || (int)(*late_seg)[k] == want_late); };
   size_t i = 0, n = m->segs.size();
   while (i < n) {
-    if (!m->segs[i].trainable) { ++i; continue; }
+    if (!take(i)) { ++i; continue; }
     size_t j = i;
-    while (j + 1 < n && m->segs[j + 1].trainable) ++j;
+    while (j + 1 < n && take(j + 1)) ++j;
     int64_t beg = m->segs[i].offset;
     int64_t end = (j + 1 < n) ? m->segs[j + 1].offset : m->total;
     FC_TRY(fc_adamw(p + beg, g + beg, mm + beg, vv + beg, (size_t)(end - beg), lr, b1, b2, eps, wd, step, shadow ? shadow + beg : nullptr, 0, s));
@@ -1068,7 +1091,12 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
     FC_TRY(fc_ce_fwd_bwd(w.t[i].logits, labels, B, m->tw[i].ncls, lossbuf, w.dout[i], s));
     (i == 0 ? d0 : d1) = w.dout[i];
   }
-  FC_TRY(backward_impl(m, params, wc, d0, d1, grads, w, s));
+  bool aux_any = false;
+  for (const fc_segment& sg : m->segs)
+    if (strstr(sg.name, "aux_weight")) aux_any = true;
+  static const bool late_opt = !(getenv("FC_LATE_OPT") && atoi(getenv("FC_LATE_OPT")) == 0);
+  LateDw late;
+  FC_TRY(backward_impl(m, params, wc, d0, d1, grads, w, s, (late_opt && !aux_any && !global_params) ? &late : nullptr));
   if (global_params)   // FedproxClient.update: loss += mu * 0.5 * sum ||p - p_global||, before the optimizer step (fedproxclient.py:64-72)
     FC_TRY(fc_prox_term(m, params, global_params, mu, B, grads, lossbuf, prox_scratch, prox_scratch_bytes, stream));
   // compute weights for the next step: without re-param linears and with every segment trainable the bf16 shadow is written
@@ -1079,7 +1107,15 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
     if (!sg.trainable) all_trainable = false;
   }
   const bool fuse_shadow = m->need_wc && m->dt == FC_BF16 && !has_aux && all_trainable;
-  FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s, fuse_shadow ? (bf16_t*)wc : nullptr));
+  if (late.pending) {   // everything that does not wait for the last weight-gradient chunk, then the chunk, then the rest
+    FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s, fuse_shadow ? (bf16_t*)wc : nullptr,
+                        &late.late_seg, 0));
+    FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
+    FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s, fuse_shadow ? (bf16_t*)wc : nullptr,
+                        &late.late_seg, 1));
+  } else {
+    FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s, fuse_shadow ? (bf16_t*)wc : nullptr));
+  }
   if (m->need_wc && !fuse_shadow) FC_TRY(fc_prepare_weights(m, params, wc, stream));
   return 0;
 }
