@@ -553,15 +553,6 @@ __global__ void __launch_bounds__(64) k_con_lse(const float* __restrict__ L, flo
     atomicAdd(lossbuf + 0, contrib * (float)B);
   }
 }
-__global__ void __launch_bounds__(256) k_con_dl(const float* __restrict__ L, const float* __restrict__ lse_r, const float* __restrict__ lse_c,
-                                                float* __restrict__ dL, int B) {
-  size_t n = (size_t)B * B;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
-    int i = (int)(idx / B), j = (int)(idx % B);
-    float l = L[idx];
-    dL[idx] = (0.5f / (float)B) * (expf(l - lse_r[i]) + expf(l - lse_c[j]) - (i == j ? 2.0f : 0.0f));
-  }
-}
 // L[i][j] = tau * <a_i, b_j>: one block per row i, thread t -> column t>>2, quarter t&3 of the feature range
 __global__ void __launch_bounds__(256) k_con_logits(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ L, int B, int D, float tau) {
   const int i = blockIdx.x, q = threadIdx.x & 3;

@@ -243,83 +243,6 @@ __device__ __forceinline__ void acc_to_lds(float* Cs, const f32x4 (&acc)[4][4], 
 // s_waitcnt vmcnt(0), which also drained the register prefetch pipeline: 17k cycles per tile instead of ~2k.)
 enum { EPI_PLAIN = 0, EPI_BIAS, EPI_RES, EPI_RES_SCALE, EPI_GELU, EPI_GELU_GRAD, EPI_PATCH, EPI_GENERIC, EPI_GELU_SG, EPI_MUL };
 
-template <int EPI, typename TC>
-__device__ __forceinline__ void tile_epilogue(const float* Cs, TC* C, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid) {
-  const int c8 = (tid & 15) * 8, n = n0 + c8, r0 = tid >> 4;
-  if (EPI == EPI_GENERIC) {
-    if (n >= N) return;
-#pragma unroll 1
-    for (int p = 0; p < 8; ++p) {
-      int row = r0 + 16 * p, m = m0 + row;
-      if (m < M) {
-        float v[8];
-        float4 x0 = *(const float4*)(Cs + row * CS_LD + c8), x1 = *(const float4*)(Cs + row * CS_LD + c8 + 4);
-        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-        epi_store8<TC>(C, ldc, m, n, v, e, N);
-      }
-    }
-    return;
-  }
-  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_GELU_SG || EPI == EPI_PATCH;
-  constexpr bool HAS_RES = EPI == EPI_RES || EPI == EPI_RES_SCALE;
-  const int nc = n < N ? n : N - 8;                     // clamped column for the loads
-  float bias[8];
-  if (HAS_BIAS) Vec8<float>::ld(e.bias + nc, bias);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    float rin[4][8], rpos[4][8], sc[4];
-    size_t off[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {                         // request every input of the batch first
-      const int m = m0 + r0 + 16 * (half * 4 + q);
-      const int mc = m < M ? m : M - 1;
-      long orow = mc;
-      if (EPI == EPI_PATCH) orow = (long)mc + mc / e.patch_rows + 1;
-      off[q] = (size_t)orow * ldc + nc;
-      if (HAS_RES) Vec8<TC>::ld((const TC*)e.res + off[q], rin[q]);
-      if (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) Vec8<TC>::ld((const TC*)e.gelu_in + off[q], rin[q]);
-      if (EPI == EPI_PATCH) Vec8<float>::ld(e.pos + (size_t)(1 + mc % e.patch_rows) * N + nc, rpos[q]);
-      if (EPI == EPI_RES_SCALE) sc[q] = e.rowscale[mc / e.rows_per_sample];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = r0 + 16 * (half * 4 + q);
-      float v[8];
-      float4 x0 = *(const float4*)(Cs + row * CS_LD + c8), x1 = *(const float4*)(Cs + row * CS_LD + c8 + 4);
-      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
-      if (HAS_BIAS) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += bias[i];
-      }
-      if (EPI == EPI_PATCH) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += rpos[q][i];
-      }
-      const bool ok = (m0 + row < M) && (n < N);
-      if (EPI == EPI_GELU) {
-        if (ok) Vec8<TC>::st((TC*)e.preact + off[q], v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_fast(v[i]);
-      }
-      if (EPI == EPI_GELU_GRAD) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= gelu_fast_grad(rin[q][i]);
-      }
-      if (EPI == EPI_RES_SCALE) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= sc[q];
-      }
-      if (HAS_RES) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += rin[q][i];
-      }
-      if (ok) Vec8<TC>::st(C + off[q], v);
-    }
-  }
-}
-
 // ---- direct-to-LDS staging (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write.  One wave-instruction fills 1 KB
 // of LDS linearly (lane L -> base + 16 L), so the swizzle is applied to the per-lane SOURCE address instead: wave w owns
 // the 1-KB pieces 4w .. 4w+3 of each 16-KB operand tile.
