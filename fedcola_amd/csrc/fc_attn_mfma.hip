@@ -157,14 +157,14 @@ __device__ __forceinline__ float dot8(const bf16x8& a, const bf16x8& b) {
 }
 
 template <int NF>
-__global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bid, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N,
+                                                 int H, float scale) {
   constexpr int NP = 16 * NF;
   char* Ks = smem;
   char* Vs = smem + NP * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
-  const int bh = blockIdx.x >> 1, part = blockIdx.x & 1;
+  const int bh = bid >> 1, part = bid & 1;
   const int b = bh / H, h = bh % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
@@ -223,16 +223,16 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
 }
 
 template <int NF>
-__global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bid, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N,
+                                                  int H, float scale) {
   constexpr int NP = 16 * NF;
   char* Qs = smem;
   char* Ds = smem + NP * 128;
   float* lse_s = (float*)(Ds + NP * 128);
   float* del_s = lse_s + NP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
-  const int bh = blockIdx.x >> 1, part = blockIdx.x & 1;
+  const int bh = bid >> 1, part = bid & 1;
   const int b = bh / H, h = bh % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
@@ -334,20 +334,28 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, in
   FC_LAUNCH_CHECK();
   return 0;
 }
+// dQ and dK/dV of one attention backward in ONE launch: blocks [0, 2BH) run the dQ half-tiles, blocks [2BH, 4BH) the dK/dV ones.
+// The two are independent; as separate launches on one stream the second waited for the first to drain.
+template <int NF>
+__global__ void __launch_bounds__(256, 2) k_attn_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                     const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int half = 2 * B * H;
+  if ((int)blockIdx.x < half) attn_bwd_dq_body<NF>(smem, blockIdx.x, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  else attn_bwd_dkv_body<NF>(smem, blockIdx.x - half, qkv, o, dout, lse, dqkv, B, N, H, scale);
+}
 template <int NF>
 static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, bf16_t* dqkv, int B, int N, int H, float scale,
                       hipStream_t s) {
   const int lds_q = 2 * 16 * NF * 128, lds_kv = 2 * 16 * NF * 128 + 2 * 16 * NF * 4;
-  auto kq = k_attn_bwd_dq<NF>;
-  auto kkv = k_attn_bwd_dkv<NF>;
+  auto kb = k_attn_bwd<NF>;
+  const int lds = lds_kv > lds_q ? lds_kv : lds_q;
   static bool done = false;
   if (!done) {
-    FC_CHECK_HIP(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q));
-    FC_CHECK_HIP(hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
   }
-  hipLaunchKernelGGL(kq, dim3(B * H * 2), dim3(256), lds_q, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
-  hipLaunchKernelGGL(kkv, dim3(B * H * 2), dim3(256), lds_kv, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  hipLaunchKernelGGL(kb, dim3(B * H * 4), dim3(256), lds, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
   FC_LAUNCH_CHECK();
   return 0;
 }
