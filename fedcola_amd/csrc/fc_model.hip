@@ -864,6 +864,17 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
             for (size_t k = 0; off >= 0 && k < m->segs.size(); ++k)
               if (m->segs[k].offset == off) late->late_seg[k] = 1;
         }
+        // whole blocks, not single tensors: otherwise the first optimizer phase fragments into a dozen small launches around
+        // the late weights (LayerNorm parameters of a late block simply wait for the second phase)
+        for (size_t k = 0; k < m->segs.size(); ++k) {
+          if (!late->late_seg[k] || strncmp(m->segs[k].name, "blockses.", 9) != 0) continue;
+          const char* dot = strchr(m->segs[k].name + 9, '.');
+          dot = dot ? strchr(dot + 1, '.') : nullptr;
+          if (!dot) continue;
+          const size_t plen = (size_t)(dot - m->segs[k].name) + 1;              // "blockses.<tower>.<layer>."
+          for (size_t j = 0; j < m->segs.size(); ++j)
+            if (strncmp(m->segs[j].name, m->segs[k].name, plen) == 0) late->late_seg[j] = 1;
+        }
         late->pending = true;
       }
       FC_TRY(flush_dw(cf_));
