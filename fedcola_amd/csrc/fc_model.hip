@@ -603,7 +603,7 @@ static int forward_impl(const fc_model* m, const float* params, const void* wc, 
     FC_TRY(fork_side(m, s));
     Ctx c2 = c;
     c2.s = m->side;
-    FC_TRY(tower_forward(c2, w, 1, nullptr, ids, feat_out, out_txt));
+    { static const char* ab = getenv("FC_ABLATE"); if (!(ab && strstr(ab, "txt"))) FC_TRY(tower_forward(c2, w, 1, nullptr, ids, feat_out, out_txt)); }   // (measurement aid)
     const int nmb = microbatches(m, B);
     if (nmb > 1) {
       const size_t ipx = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
@@ -828,7 +828,7 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     FC_TRY(fork_side(m, s));
     Ctx c2 = c;
     c2.s = m->side;
-    FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads));      // text tower (short) first: its dW chunks start early
+    { static const char* ab = getenv("FC_ABLATE"); if (!(ab && strstr(ab, "txt"))) FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads)); }   // text tower (short) first: its dW chunks start early
     const int nmb = c.defer ? microbatches(m, w.B) : 1;
     if (nmb > 1) {
       // image tower as micro-batch chains, interleaved layer by layer; the full-batch weight gradients of a layer are
