@@ -119,3 +119,22 @@ def test_errors_are_loud():
     cpu_model = PU.build_product(rec["mk"], "fp32", G.case_weights("imgcls_aux")).cpu()
     with pytest.raises(FedcolaHipError):
         cpu_model([torch.zeros(2, 3, 224, 224), None])                   # no CPU fallback
+
+
+def test_microbatch_chains_do_not_change_the_result(tmp_path):
+    """The image tower runs as two micro-batch chains by default (FC_MICROBATCH, read once per process): an odd batch (B = 17 ->
+    8 + 9) gives the same gradients as the single-chain run up to the order of the LayerNorm partial sums."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mb in ("1", "2"):
+        f = str(tmp_path / f"mb{mb}.pt")
+        env = dict(os.environ, FC_MICROBATCH=mb)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mb_check.py"), "17", f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mb] = torch.load(f)
+    for k in out["1"]:
+        scale = max(float(out["1"][k].abs().max()), 1e-9)
+        assert float((out["1"][k] - out["2"][k]).abs().max()) <= 2e-5 * scale, k
