@@ -12,6 +12,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+    # the C-ABI library is a build artefact (git-ignored): make sure it exists and is current before any test loads it
+    try:
+        from fedcola_amd import build as _b
+        if _b.needs_build() and os.path.exists(_b.HIPCC):
+            _b.build(force=False, verbose=False)
+    except Exception as e:  # a failed build surfaces in the tests that need the library
+        print(f"[conftest] building libfedcola_hip.so failed: {e}", file=sys.stderr)
 
 
 def pytest_collection_modifyitems(config, items):
