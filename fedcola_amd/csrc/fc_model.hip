@@ -61,16 +61,13 @@ struct fc_model {
   mutable hipStream_t mbs[3] = {nullptr, nullptr, nullptr};      // micro-batch chains 1..3 (chain 0 runs on the caller's stream)
   mutable hipEvent_t ev_mb_join[3] = {nullptr, nullptr, nullptr};
   ~fc_model() {
-    if (dws) (void)hipStreamDestroy(dws);
     if (ev_dw_in) (void)hipEventDestroy(ev_dw_in);
     for (int k = 0; k < 3; ++k) {
       if (ev_dw_in2[k]) (void)hipEventDestroy(ev_dw_in2[k]);
-      if (mbs[k]) (void)hipStreamDestroy(mbs[k]);
       if (ev_mb_join[k]) (void)hipEventDestroy(ev_mb_join[k]);
     }
     if (ev_dw_out) (void)hipEventDestroy(ev_dw_out);
     if (ev_dw_prev) (void)hipEventDestroy(ev_dw_prev);
-    if (side) (void)hipStreamDestroy(side);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
   }
@@ -537,23 +534,85 @@ static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int
   return 0;
 }
 
-static int ensure_side(const fc_model* m) {
+// ---- the library's internal streams: ONE set per device for the whole process, chosen by measurement.
+// HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order; two streams that share a
+// queue serialise.  Which queue a new stream gets depends on every stream the process created before (torch's pool, other
+// handles), and a collision costs a third of the throughput (ViT-S step 5.5 ms -> 7.2 ms).  So candidates are created and TESTED:
+// a stream is accepted only if a spin kernel on it overlaps with spin kernels on the caller's stream and on every stream
+// accepted so far.  Streams beyond the distinct queues available are accepted untested.
+__global__ void k_spin(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+static bool streams_overlap(hipStream_t a, hipStream_t b) {
+  hipEvent_t e0, e1, eb;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess)
+    return true;
+  const long long ticks = 8000;      // 80 us at the 100 MHz wall clock
+  (void)hipStreamSynchronize(a);
+  (void)hipStreamSynchronize(b);
+  (void)hipEventRecord(e0, a);
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
+  (void)hipEventRecord(eb, b);
+  (void)hipStreamWaitEvent(a, eb, 0);
+  (void)hipEventRecord(e1, a);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(eb);
+  return ms < 0.130f;               // concurrent: ~0.08 ms, serialised: ~0.16 ms
+}
+struct StreamSet { hipStream_t s[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int n = 0; };
+static StreamSet& device_streams(hipStream_t caller, int want) {
+  static StreamSet sets[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  StreamSet& S = sets[dev & 15];
+  static const bool calibrate = !(getenv("FC_STREAM_CALIBRATE") && atoi(getenv("FC_STREAM_CALIBRATE")) == 0);
+  int tested_ok = 0;
+  while (S.n < want) {
+    hipStream_t pick = nullptr;
+    std::vector<hipStream_t> rejected;
+    for (int attempt = 0; attempt < 8 && !pick; ++attempt) {
+      hipStream_t c = nullptr;
+      if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+      bool ok = true;
+      if (calibrate && S.n < 3) {          // caller + 3 = the four queues; later streams cannot all be distinct anyway
+        ok = streams_overlap(caller, c);
+        for (int i = 0; ok && i < S.n; ++i) ok = streams_overlap(S.s[i], c);
+      }
+      if (ok) pick = c; else rejected.push_back(c);
+    }
+    if (!pick) {                            // no collision-free queue found: take a fresh stream as it comes
+      if (hipStreamCreateWithFlags(&pick, hipStreamNonBlocking) != hipSuccess) break;
+    } else {
+      ++tested_ok;
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    S.s[S.n++] = pick;
+  }
+  (void)tested_ok;
+  return S;
+}
+static int ensure_side(const fc_model* m, hipStream_t caller = nullptr) {
   if (!m->dws) {
-    FC_CHECK_HIP(hipStreamCreateWithFlags(&m->dws, hipStreamNonBlocking));
-    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in, hipEventDisableTiming));
-    // (HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default: caller + text + dW + one extra chain
-    // fill them; streams beyond that share a queue and serialise, so only the chains that are used get a stream)
     static int req = getenv("FC_MICROBATCH") ? atoi(getenv("FC_MICROBATCH")) : 2;
-    for (int k = 0; k < 3 && k < (req > 4 ? 4 : req) - 1; ++k) {
+    const int nmb = (req > 4 ? 4 : (req < 1 ? 1 : req)) - 1;          // extra image chains
+    StreamSet& S = device_streams(caller, 2 + (nmb > 1 ? nmb : 1));
+    FC_REQUIRE(S.n >= 3, "could not create the internal HIP streams");
+    // order of preference for collision-free queues: weight gradients, first extra image chain, text tower
+    m->dws = S.s[0];
+    m->mbs[0] = nmb >= 1 ? S.s[1] : nullptr;
+    m->side = S.s[2];
+    for (int k = 1; k < 3; ++k) m->mbs[k] = (k < nmb && 2 + k < S.n) ? S.s[2 + k] : nullptr;
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in, hipEventDisableTiming));
+    for (int k = 0; k < 3; ++k) {
       FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in2[k], hipEventDisableTiming));
-      FC_CHECK_HIP(hipStreamCreateWithFlags(&m->mbs[k], hipStreamNonBlocking));
       FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_mb_join[k], hipEventDisableTiming));
     }
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_out, hipEventDisableTiming));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_prev, hipEventDisableTiming));
-  }
-  if (!m->side) {
-    FC_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   }
@@ -564,7 +623,7 @@ extern "C" void* fc_model_side_stream(const fc_model_t* m) {
   return (void*)m->side;
 }
 static int fork_side(const fc_model* m, hipStream_t s) {   // side (text tower) and micro-batch streams start after `s`
-  FC_TRY(ensure_side(m));
+  FC_TRY(ensure_side(m, s));
   FC_CHECK_HIP(hipEventRecord(m->ev_fork, s));
   FC_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
   for (int k = 0; k < 3 && m->mbs[k]; ++k) FC_CHECK_HIP(hipStreamWaitEvent(m->mbs[k], m->ev_fork, 0));
@@ -816,7 +875,7 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
   std::vector<FcLnReduce> lnq;
   DwState dwst;
   if (m->dt == FC_BF16) {   // dW / db products are queued and launched in grouped chunks on the dW stream
-    FC_TRY(ensure_side(m));
+    FC_TRY(ensure_side(m, s));
     c.defer = &probs;
     dwst.dev = w.probs;
     dwst.max_probs = w.max_probs;
