@@ -578,7 +578,8 @@ static StreamSet& device_streams(hipStream_t caller, int want) {
       hipStream_t c = nullptr;
       if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
       bool ok = true;
-      if (calibrate && S.n < 3) {          // caller + 3 = the four queues; later streams cannot all be distinct anyway
+      static const int hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+      if (calibrate && S.n < hwq - 1) {    // caller + (queues - 1) streams can be distinct; later ones cannot
         ok = streams_overlap(caller, c);
         for (int i = 0; ok && i < S.n; ++i) ok = streams_overlap(S.s[i], c);
       }
