@@ -9,8 +9,9 @@ Per round (``update``, creamflserver.py:338-435):
      then KD distillation to the aggregated features: MSE, clip 2, AdamW(p_lr) -> fc_forward / fc_mse_loss_fwd_bwd / fc_backward /
      fc_clip_grad_norm / fc_adamw_step
   5. uni-modal global models: ``FedavgServer._aggregate(fedavg=True)``.
-The public set itself is injected (``args.pub_dataset``: samples ``(image, tokens, image_id, ann_id, index)``): the reference builds it
-from COCO annotation files through pycocotools (creamflserver.py:100-126), which this build does not parse."""
+The public set is ``args.pub_dataset`` when given (samples ``(image, tokens, image_id, ann_id, index)``), else the COCO split the reference
+builds (creamflserver.py:100-126) through ``fedcola_amd.datasets.coco.public_set`` (image transform / tokenizer: ``args.pub_transform``,
+``args.pub_tokenizer`` -- the reference hard-wires torchvision transforms and the HF BertTokenizer there)."""
 from __future__ import annotations
 
 import logging
@@ -29,9 +30,10 @@ logger = logging.getLogger(__name__)
 class CreamflServer(FedavgServer):
     def __init__(self, args, writer, server_dataset, client_datasets, model_str):
         pub = getattr(args, "pub_dataset", None)
-        if pub is None:
-            raise NotImplementedError("CreamflServer needs args.pub_dataset (the public image-caption set); building it from COCO "
-                                      "annotation files (pycocotools) is outside this build")
+        if pub is None:                                           # creamflserver.py:100-113: the COCO public split
+            from ..datasets.coco import public_set
+            pub = public_set(args.pub_data_dir, args.pub_anno_path, args.num_pub_samples, transform=getattr(args, "pub_transform", None),
+                             tokenizer=getattr(args, "pub_tokenizer", None), max_length=args.seq_len)
         self.pub_dataset = pub
         self.pub_loader = data.DataLoader(dataset=pub, batch_size=args.pub_batch_size, shuffle=False, drop_last=False)
         super().__init__(args, writer, server_dataset, client_datasets, model_str)

@@ -101,3 +101,52 @@ def test_device_prefetcher_order_and_values():
             assert float(x.mean()) == float(i) and int(y[0, 0]) == i
     with pytest.raises(RuntimeError):
         list(DevicePrefetcher(batches, "cpu"))
+
+
+def _make_coco(root, n_images=4, caps=5):
+    from PIL import Image
+    os.makedirs(os.path.join(root, "all_images"), exist_ok=True)
+    os.makedirs(os.path.join(root, "annotations"), exist_ok=True)
+    for split, base in (("train", 100), ("val", 500)):
+        images, anns = [], []
+        for i in range(n_images):
+            iid = base + 7 * i
+            fn = f"COCO_{split}2014_{iid:012d}.jpg"
+            Image.fromarray(((np.arange(8 * 8 * 3).reshape(8, 8, 3) + iid) % 255).astype(np.uint8)).save(os.path.join(root, "all_images", fn.replace(".jpg", ".png")))
+            os.replace(os.path.join(root, "all_images", fn.replace(".jpg", ".png")), os.path.join(root, "all_images", fn))
+            images.append({"id": iid, "file_name": fn})
+            for j in range(caps):
+                anns.append({"id": 10 * iid + j, "image_id": iid, "caption": f"caption {j} of image {iid}"})
+        with open(os.path.join(root, "annotations", f"captions_{split}2014.json"), "w") as f:
+            json.dump({"info": {}, "images": images, "annotations": anns}, f)
+        np.save(os.path.join(root, f"coco_{'train' if split == 'train' else 'test'}_ids.npy"), np.array([a["id"] for a in anns], dtype=np.int64))
+    os.makedirs(os.path.join(root, "inst"), exist_ok=True)
+    with open(os.path.join(root, "inst", "instances_train2014.json"), "w") as f:
+        json.dump({"annotations": [{"image_id": 100, "category_id": 3}, {"image_id": 107, "category_id": 3}, {"image_id": 114, "category_id": 90},
+                                   {"image_id": 121, "category_id": 1}, {"image_id": 121, "category_id": 3}]}, f)
+
+
+def test_coco_format(tmp_path):
+    """COCO caption annotations without pycocotools (parity unpinned there: the published annotation format is the contract)."""
+    from fedcola_amd.datasets.coco import CocoCaptionsCap, fetch_coco, public_set
+    root = str(tmp_path)
+    _make_coco(root)
+    to_t = lambda im: torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1)
+    ann = os.path.join(root, "annotations", "captions_train2014.json")
+    ds = CocoCaptionsCap(os.path.join(root, "all_images"), ann, transform=to_t, tokenizer=_tok, max_length=8)
+    assert len(ds) == 20 and ds.n_images == 4 and ds.iid_to_cls == {}
+    img, cap, iid, aid, idx = ds[7]
+    assert (iid, aid, idx) == (107, 1072, 7) and tuple(img.shape) == (3, 8, 8) and cap.shape == (8,)
+    sub = CocoCaptionsCap(os.path.join(root, "all_images"), ann, ids=np.array([1000, 1141, 1142]), extra_ids=[1210])
+    assert sub.ids == [1000, 1141, 1142, 1210] and sub.n_images == 3 and sub[1][1] == "caption 1 of image 114"
+    sub.reduce_samples(2)
+    assert sub.ids == [1142, 1210]
+    cls = CocoCaptionsCap(os.path.join(root, "all_images"), ann, instance_annFile=os.path.join(root, "inst"))
+    assert cls.iid_to_cls == {100: 0, 107: 0, 114: 1, 121: 2}          # same category code -> same dense class, first-seen order
+    merged = CocoCaptionsCap(os.path.join(root, "all_images"), ann, extra_annFile=os.path.join(root, "annotations", "captions_val2014.json"))
+    assert len(merged) == 40 and merged.n_images == 8
+    a = RefArgs(seq_len=8, reduce_samples=10)
+    tr, te, a2 = fetch_coco(a, root, (to_t, to_t), _tok)
+    assert len(tr) == 10 and len(te) == 20 and tr.name == "Coco" and a2.num_classes is None
+    pub = public_set(os.path.join(root, "all_images"), root + "/annotations/captions_train2014.json", 6, transform=to_t, tokenizer=_tok, max_length=8)
+    assert pub.ids == [1144, 1210, 1211, 1212, 1213, 1214]          # the LAST ids of coco_train_ids.npy
