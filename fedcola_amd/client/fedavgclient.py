@@ -49,6 +49,9 @@ class FedavgClient(BaseClient):
     def _create_dataloader(self, dataset, shuffle, test=True):
         if self.args.B == 0:
             self.args.B = len(self.training_set)
+        if getattr(self.args, "fast_loader", False):                 # same sampling, threaded assembly into pinned buffers (loaders/batch.py)
+            from ..loaders.batch import PinnedBatchLoader
+            return PinnedBatchLoader(dataset, self.args.B, shuffle=shuffle, workers=getattr(self.args, "loader_workers", 8))
         return torch.utils.data.DataLoader(dataset=dataset, batch_size=self.args.B, shuffle=shuffle)
 
     # ------------------------------------------------------------------ the hot loop (fedavgclient.py:55-116)

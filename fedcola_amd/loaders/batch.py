@@ -1,0 +1,92 @@
+"""Host-side batch assembly for the client loops.
+
+The reference iterates a single-process ``DataLoader(dataset, batch_size, shuffle)`` (src/client/fedavgclient.py:44-53): 64 samples
+are fetched one by one and ``default_collate`` stacks them into a new pageable tensor -- ~100 ms for a B = 64 batch of 224x224
+fp32 images on the GPU box's host, 18x the device step.  ``PinnedBatchLoader`` keeps the reference's sampling exactly (torch's
+``RandomSampler`` / ``SequentialSampler`` + ``BatchSampler``: the same index order under the same RNG state) but has worker
+threads write every sample straight into a pinned batch buffer (tensor copies release the GIL); the buffers come from torch's
+caching pinned allocator, which does not recycle a block while an asynchronous H2D copy from it is in flight, so the batches can
+be handed to ``DevicePrefetcher`` as they are.  A dataset may offer ``get_batch(indices) -> tuple of stacked fields`` (same fields as
+``__getitem__``); then the per-sample Python overhead (the remaining ~20 ms per batch) disappears as well."""
+from __future__ import annotations
+
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
+
+
+class PinnedBatchLoader:
+    def __init__(self, dataset, batch_size: int, shuffle: bool = False, drop_last: bool = False, workers: int = 8, pin: bool = True, ahead: int = 2):
+        self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
+        self.workers, self.pin, self.ahead = max(1, int(workers)), pin and torch.cuda.is_available(), max(0, int(ahead))
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _fill(self, bufs, j, i):
+        item = self.dataset[i]
+        for f, v in enumerate(item):
+            bufs[f][j].copy_(torch.as_tensor(v))
+
+    def __iter__(self):
+        # DataLoader.__iter__ draws its base seed from the default RNG before the sampler draws the permutation seed: consume the
+        # same number so that a shuffled epoch visits the samples in exactly the DataLoader's order under the same RNG state
+        torch.empty((), dtype=torch.int64).random_()
+        sampler = RandomSampler(self.dataset) if self.shuffle else SequentialSampler(self.dataset)
+        batches = list(BatchSampler(sampler, self.batch_size, self.drop_last))      # every RNG draw happens here, in the caller's thread
+
+        def assemble(pool, idxs):
+            if hasattr(self.dataset, "get_batch"):          # vectorised fetch (in-memory / pre-decoded datasets): one gather per field
+                fields = [torch.as_tensor(v) for v in self.dataset.get_batch(idxs)]
+                bufs = [torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=self.pin) for t in fields]
+                list(pool.map(lambda bt: bt[0].copy_(bt[1]), zip(bufs, fields)))
+                return tuple(bufs)
+            first = [torch.as_tensor(v) for v in self.dataset[idxs[0]]]
+            bufs = [torch.empty((len(idxs),) + tuple(t.shape), dtype=t.dtype, pin_memory=self.pin) for t in first]
+            for f, t in enumerate(first):
+                bufs[f][0].copy_(t)
+            list(pool.map(lambda ji: self._fill(bufs, ji[0] + 1, ji[1]), enumerate(idxs[1:])))
+            return tuple(bufs)
+
+        if self.ahead == 0:
+            with ThreadPoolExecutor(self.workers) as pool:
+                for idxs in batches:
+                    yield assemble(pool, idxs)
+            return
+        # a producer thread assembles `ahead` batches in advance, under the consumer's device work
+        q: "queue.Queue" = queue.Queue(maxsize=self.ahead)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                with ThreadPoolExecutor(self.workers) as pool:
+                    for idxs in batches:
+                        if stop.is_set():
+                            return
+                        q.put(assemble(pool, idxs))
+                q.put(None)
+            except BaseException as e:      # surfaces in the consumer
+                q.put(e)
+
+        t = threading.Thread(target=produce, daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            while t.is_alive():             # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.05)

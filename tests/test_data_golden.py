@@ -150,3 +150,38 @@ def test_coco_format(tmp_path):
     assert len(tr) == 10 and len(te) == 20 and tr.name == "Coco" and a2.num_classes is None
     pub = public_set(os.path.join(root, "all_images"), root + "/annotations/captions_train2014.json", 6, transform=to_t, tokenizer=_tok, max_length=8)
     assert pub.ids == [1144, 1210, 1211, 1212, 1213, 1214]          # the LAST ids of coco_train_ids.npy
+
+
+def test_pinned_batch_loader_yields_the_dataloaders_batches():
+    """Same sampler, same RNG state -> the same batches as torch's DataLoader (shuffled and sequential, ragged last batch, mixed fields)."""
+    from fedcola_amd.loaders.batch import PinnedBatchLoader
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            return torch.full((3, 5, 5), float(i)), torch.arange(4) + i, i // 5, i, i
+
+    for shuffle in (False, True):
+        torch.manual_seed(11)
+        ref = list(torch.utils.data.DataLoader(DS(), batch_size=6, shuffle=shuffle))
+        torch.manual_seed(11)
+        got = list(PinnedBatchLoader(DS(), 6, shuffle=shuffle, workers=4))
+        assert len(got) == len(ref) == 4 and len(PinnedBatchLoader(DS(), 6)) == 4
+        for a, b in zip(got, ref):
+            assert len(a) == len(b) == 5
+            for x, y in zip(a, b):
+                assert x.dtype == y.dtype and torch.equal(x, y)
+    assert len(list(PinnedBatchLoader(DS(), 6, drop_last=True))) == 3
+
+    class DSB(DS):
+        def get_batch(self, idxs):
+            i = torch.as_tensor(idxs)
+            return torch.stack([torch.full((3, 5, 5), float(k)) for k in idxs]), torch.arange(4)[None, :] + i[:, None], i // 5, i, i
+    torch.manual_seed(11)
+    ref = list(torch.utils.data.DataLoader(DS(), batch_size=6, shuffle=True))
+    torch.manual_seed(11)
+    for a, b in zip(PinnedBatchLoader(DSB(), 6, shuffle=True, ahead=0), ref):
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and torch.equal(x, y)
