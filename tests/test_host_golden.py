@@ -182,3 +182,16 @@ def test_model_layout_and_errors_without_gpu():
     with pytest.raises(ValueError):
         M(modalities=["img", None], num_classes=[3, None], tasks=["cls", None], embed_dim=8, depth=1, num_heads=2, with_aux=True,
           aux_attn_only=True, aux_mlp_only=True)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/fedcola_hip.h is the drop-in boundary: it must compile as C99 (no C++ / torch types in the signatures)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "fedcola_hip.h"\nint main(void) { fc_model_cfg c; (void)c; return FC_ABI_VERSION == 1 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
