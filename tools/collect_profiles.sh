@@ -11,6 +11,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
 python tools/prof_summary.py "$OUT/trace" 35 40 > "$OUT/bench_summary.txt" 2>&1
 cp "$OUT"/trace/bench_kernel_stats.csv "$OUT/bench_kernel_stats.csv" 2>/dev/null
 cp "$OUT"/trace/bench_domain_stats.csv "$OUT/bench_domain_stats.csv" 2>/dev/null
+# 2b. the roofline kernel alone (the probe bench.py times with HIP events): its average duration in this summary is the one to compare
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/gtrace" -o g -- python3 tools/gemm_bench.py 30 "NT fc1" > "$OUT/gtrace.log" 2>&1
+cp "$OUT"/gtrace/g_kernel_stats.csv "$OUT/gemm_fc1_kernel_stats.csv" 2>/dev/null
 # 3. counters of the dominant kernel, one counter set per pass
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" SQ_LDS_BANK_CONFLICT; do
   tag=$(echo $c | tr ' ' '_')
@@ -26,6 +29,6 @@ done
 timeout 200 python tools/retrieval_bench.py 5 2>/dev/null > "$OUT/retrieval_bench.txt"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rtrace" -o r -- python3 tools/retrieval_bench.py 3 > "$OUT/rtrace.log" 2>&1
 python tools/prof_summary.py "$OUT/rtrace" 4 6 > "$OUT/retrieval_summary.txt" 2>&1
-rm -rf "$OUT"/trace/*trace.csv "$OUT"/rtrace "$OUT"/pmc_* "$OUT"/step_FETCH_SIZE "$OUT"/step_WRITE_SIZE "$OUT"/*.log
+rm -rf "$OUT"/trace/*trace.csv "$OUT"/gtrace "$OUT"/rtrace "$OUT"/pmc_* "$OUT"/step_FETCH_SIZE "$OUT"/step_WRITE_SIZE "$OUT"/*.log
 ls -la "$OUT"
 cat "$OUT/bench_line.json"
