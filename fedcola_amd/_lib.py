@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfedcola_hip.so")
+if os.environ.get("FC_PROBES_LIB"):      # tools only: the -DFC_PROBES build with the measurement aids (python -m fedcola_amd.build --probes)
+    LIB_PATH = os.path.join(_HERE, "libfedcola_hip_probes.so")
 
 FC_PREC_FP32, FC_PREC_BF16 = 0, 1
 FC_TASK_NONE, FC_TASK_CLS, FC_TASK_RTV = 0, 1, 2

@@ -19,18 +19,26 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in glob.glob(os.path.join(CSRC, "*")) + HEADERS)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, probes=False):
+    """probes=True: the tools build (-DFC_PROBES -> libfedcola_hip_probes.so) that carries the measurement aids (kernel-family
+    ablation, GEMM phase knobs).  The product library is built without them."""
+    if probes:
+        return _build(True, verbose, os.path.join(HERE, "libfedcola_hip_probes.so"), os.path.join(HERE, "build", "probes"), ["-DFC_PROBES"])
     if not force and not needs_build():
         return OUT
+    return _build(force, verbose, OUT, os.path.join(HERE, "build"), [])
+
+
+def _build(force, verbose, OUT, objdir, extra):
     objs, procs = [], []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in HEADERS)
     for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
             continue
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -45,5 +53,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    print(build(force="--force" in sys.argv, probes="--probes" in sys.argv))

@@ -361,7 +361,7 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, co
 }
 
 int fc_attn_fwd_mfma(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H, int d, float scale, hipStream_t s) {
-  { static const char* ab = getenv("FC_ABLATE"); if (ab && strstr(ab, "attn")) return 0; }   // measurement aid (wrong results)
+  if (FC_ABLATED("attn")) return 0;
   if (d != 64 || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 7)) return 1;
   switch (pick_nf(N)) {
     case 2: return launch_fwd<2>(qkv, o, lse, B, N, H, scale, s);
@@ -374,7 +374,7 @@ int fc_attn_fwd_mfma(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int
 
 int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv, int B, int N, int H,
                      int d, float scale, hipStream_t s) {
-  { static const char* ab = getenv("FC_ABLATE"); if (ab && strstr(ab, "attn")) return 0; }   // measurement aid (wrong results)
+  if (FC_ABLATED("attn")) return 0;
   (void)delta;   // recomputed in-kernel
   if (d != 64 || ((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)o & 15)) return 1;
   switch (pick_nf(N)) {

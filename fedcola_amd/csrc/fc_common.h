@@ -28,6 +28,19 @@ void fc_set_error(const char* fmt, ...);
     }                              \
   } while (0)
 #define FC_LAUNCH_CHECK() FC_CHECK_HIP(hipGetLastError())
+// Measurement aids (skip a kernel family, GEMM phase ablations, in-kernel stamps) exist only in the tools build
+// (-DFC_PROBES -> libfedcola_hip_probes.so, tools/build_probes.py); the product library contains none of them.
+#ifdef FC_PROBES
+#include <stdlib.h>
+#include <string.h>
+static inline bool fc_ablated(const char* what) {
+  static const char* ab = getenv("FC_ABLATE");
+  return ab && strstr(ab, what);
+}
+#define FC_ABLATED(what) fc_ablated(what)
+#else
+#define FC_ABLATED(what) false
+#endif
 #define FC_TRY(expr)          \
   do {                        \
     int _r = (expr);          \
@@ -117,6 +130,5 @@ struct GemmEpi {
   float alpha = 1.0f;               // result = alpha*acc (+bias...)
   int patch_rows = 0;               // >0: patch-embed remap: out row = m + m/patch_rows + 1, adds pos[1 + m%patch_rows]
   const float* pos = nullptr;       // [1+patch_rows, N] fp32
-  long long* stamps = nullptr;      // development: per-workgroup s_memtime stamps [grid][32]
-  int dbg = 0;                      // development ablations (FC_GEMM_DBG): 1 = no global loads in the loop, 2 = no epilogue, 4 = no MFMA
+  int dbg = 0;                      // tools build only (FC_PROBES, FC_GEMM_DBG): 1 = no global loads in the loop, 2 = no epilogue, 4 = no MFMA
 };

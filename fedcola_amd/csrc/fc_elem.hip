@@ -207,7 +207,7 @@ static bool ln_vec_ok(const void* a, const void* b, const void* c, const void* d
 
 int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int D,
                      float eps, hipStream_t s) {
-  { static const char* ab = getenv("FC_ABLATE"); if (ab && strstr(ab, "ln")) return 0; }   // measurement aid (wrong results)
+  if (FC_ABLATED("ln")) return 0;
   if (M <= 0) return 0;
   if (ln_vec_ok(x, y, g, b, D)) {
     DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_fwd_v<T>, dim3(fc_cdiv(M, 4)), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, M, D, eps));
@@ -281,7 +281,7 @@ int fc_layernorm_bwd_partial_blocks(int M) { return fc_cdiv(M, 16); }
 
 int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res,
                      void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial) {
-  { static const char* ab = getenv("FC_ABLATE"); if (ab && strstr(ab, "ln")) return 0; }   // measurement aid (wrong results)
+  if (FC_ABLATED("ln")) return 0;
   if (M <= 0) return 0;
   if (ln_vec_ok(dy, x, dx, res, D) && !((uintptr_t)g & 15)) {
     const int rpb = 16;
@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, float* __r
 }
 int fc_adamw(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd, int step,
              void* shadow_bf16, int zero_grad, hipStream_t s) {
-  { static const char* ab = getenv("FC_ABLATE"); if (ab && strstr(ab, "adamw")) return 0; }   // measurement aid (wrong results)
+  if (FC_ABLATED("adamw")) return 0;
   FC_REQUIRE(n % 4 == 0 && ((uintptr_t)p % 16 == 0), "adamw: buffer must be 16B aligned and a multiple of 4 elements");
   double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   float step_size = (float)((double)lr / bc1);

@@ -90,6 +90,10 @@ enum { FC_GEMM_NT = 0, FC_GEMM_NN = 1, FC_GEMM_TN = 2 };
 int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K,
                  const GemmEpi& epi, hipStream_t s);
 
+// weight-stationary form for K <= 384 (fc_gemm_ws.hip); returns 1 when the shape / epilogue is not covered
+int fc_gemm_ws(int kind, const bf16_t* A, long lda, const bf16_t* W, long ldw, bf16_t* C, long ldc, int M, int N, int K, const GemmEpi& epi,
+               hipStream_t s);
+
 // grouped weight-gradient GEMM: C[M,N] (fp32) = A[K,M]^T . B[K,N], bias_grad[M] = column sums of A (may be null)
 struct FcTnProblem {
   const bf16_t* A;

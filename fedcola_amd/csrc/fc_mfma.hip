@@ -5,58 +5,24 @@
 //   TN: C[M,N] = A[K,M]^T . B[K,N]     dW = dY^T . X (fp32 out)   (both operands KR; split-K over the long reduction)
 //
 // Structure: 128x128 output tile, BK = 64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16
-// accumulators.  Global -> registers -> LDS staging with the next tile's loads issued before the current tile's MFMAs
-// and written to the other LDS buffer afterwards (one barrier per k-tile).  LDS images are XOR-swizzled so that both
-// fragment read forms are bank-conflict free:
+// accumulators with swapped operands (a lane owns 4 consecutive output columns).
+//   NT / NN (k_gemm_mfma): persistent workgroups (<= 2 per CU) walk the output tiles; operand tiles stream global -> LDS by
+//   LDS-DMA (buffer_load ... lds, no staging registers), double-buffered, one barrier per k-tile; the epilogue kind is a
+//   template parameter and goes through the idle staging buffer in two 64-row halves.
+//   TN (k_gemm_tn_grouped): one workgroup per output tile over the whole (long) reduction, operands staged through
+//   registers with two k-tiles of loads in flight; every dW / db of a group of layers in one launch.
+// LDS images are XOR-swizzled (fc_mfma_dev.h) so that both fragment read forms are bank-conflict free:
 //   KC tile [128 rows][64 k]  (128 B rows): 16-B chunk c of row r lives at chunk c ^ ((r>>1)&7); fragments by ds_read_b128.
 //   KR tile [64 k][128 cols]  (256 B rows): 32-B unit u of row k lives at unit u ^ (((k>>3)&1)<<2 | (k&3)); fragments by
 //   ds_read_b64_tr_b16 (the CDNA4 transposing LDS read), two per 8-k fragment.
-// Epilogue: accumulators -> LDS (fp32, padded rows) -> 8 consecutive columns per thread -> fused bias / GELU(+pre-act
-// store) / GELU' multiply / drop-path row scale / residual / patch-embed row remap, 16-byte global stores.
 // Block ids are remapped so that the tiles sharing an A row-panel run on the same XCD (private L2).
-#include <stdlib.h>
-
+// The weight-stationary kernels for K <= 384 live in fc_gemm_ws.hip.
 #include <stdlib.h>
 #include <string.h>
 
 #include "fc_kernels.h"
+#include "fc_mfma_dev.h"
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
-// (__syncthreads() carries a release fence: with stores or loads in flight hipcc drains vmcnt(0) in front of every
-// barrier, which serialises the register prefetch pipeline and makes each epilogue wait out its own HBM write latency.)
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-#define BM 128
-#define BN 128
-#define BK 64
-#define CS_LD 132  // padded fp32 row of the epilogue image
-enum { KC = 0, KR = 1 };
-
-__device__ __forceinline__ int kc_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
-__device__ __forceinline__ int kr_off(int k, int c) {
-  int s = (((k >> 3) & 1) << 2) | (k & 3);
-  return k * 256 + (((c >> 1) ^ s) << 5) + ((c & 1) << 4);
-}
-
-// ---- staging: each thread moves 4 x 16 B per operand per k-tile.
-// Loads are raw buffer loads: one wave-uniform descriptor (SGPRs) + a 32-bit per-lane byte offset that is constant over
-// the k loop + a scalar k offset, so the address arithmetic costs no VGPRs; out-of-range rows of the last tile fall
-// outside the descriptor and read as zero in hardware.
-typedef __attribute__((vector_size(16))) unsigned int v4u;
-struct Operand {
-  __amdgpu_buffer_rsrc_t rsrc;
-  unsigned voff[4];   // per-lane byte offsets of the 4 pieces (k-independent)
-  unsigned kstride;   // bytes per k element (KC: 2) or per k row (KR: 2*ld)
-  int c8;             // KC only: first k of this lane's 16-B chunk inside a tile
-};
-#define FC_OOB 0x80000000u
 template <int MODE>
 __device__ __forceinline__ void retarget_operand(Operand& o, long ld, int row0, int nrows, int tid, bool valid) {
   // move the per-lane offsets to another tile of the same matrix (row0 = first row (KC) / first column (KR))
@@ -124,49 +90,6 @@ __device__ __forceinline__ void stage_store(const uint4 (&r)[4], char* lds, int 
   }
 }
 
-// ---- fragment reads.  rb = first row (KC) / first column (KR) of the 16-wide block inside the tile; ks = k-step (0/1)
-template <int MODE>
-__device__ __forceinline__ bf16x8 frag_read(const char* lds, int rb, int ks, int lane) {
-  if (MODE == KC) {
-    int row = rb + (lane & 15), c = ks * 4 + (lane >> 4);
-    return *(const bf16x8*)(lds + kc_off(row, c));
-  } else {
-    int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    int col = rb + 4 * p;
-    int cbyte = (col & 7) * 2, c = col >> 3;
-    int k0 = ks * 32 + 8 * g + q;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + kr_off(k0, c) + cbyte));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + kr_off(k0 + 4, c) + cbyte));
-    bf16x8 f;
-    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-    return f;
-  }
-}
-
-// ---- epilogue on 8 consecutive columns of one row
-template <typename TC> struct Vec8;
-template <> struct Vec8<bf16_t> {
-  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
-    uint4 u = *(const uint4*)p;
-    const bf16_t* h = (const bf16_t*)&u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = bf2f(h[i]);
-  }
-  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
-    *(uint4*)p = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
-  }
-};
-template <> struct Vec8<float> {
-  static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
-    float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  }
-  static __device__ __forceinline__ void st(float* p, const float (&v)[8]) {
-    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
-    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  }
-};
 
 template <typename TC>
 __device__ __forceinline__ void epi_store8(TC* C, long ldc, int m, int n, float (&v)[8], const GemmEpi& e, int N) {
@@ -243,58 +166,6 @@ __device__ __forceinline__ void acc_to_lds(float* Cs, const f32x4 (&acc)[4][4], 
 // s_waitcnt vmcnt(0), which also drained the register prefetch pipeline: 17k cycles per tile instead of ~2k.)
 enum { EPI_PLAIN = 0, EPI_BIAS, EPI_RES, EPI_RES_SCALE, EPI_GELU, EPI_GELU_GRAD, EPI_PATCH, EPI_GENERIC, EPI_GELU_SG, EPI_MUL };
 
-// ---- direct-to-LDS staging (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write.  One wave-instruction fills 1 KB
-// of LDS linearly (lane L -> base + 16 L), so the swizzle is applied to the per-lane SOURCE address instead: wave w owns
-// the 1-KB pieces 4w .. 4w+3 of each 16-KB operand tile.
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <int MODE>
-__device__ __forceinline__ Operand make_operand_glds(const bf16_t* P, long ld, int row0, int nrows, int K, int wave, int lane) {
-  Operand o;
-  unsigned long long base = (unsigned long long)P;
-  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-  const void* up = (const void*)(((unsigned long long)hi << 32) | lo);
-  long rows = (MODE == KC) ? nrows : K;
-  unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(((rows - 1) * ld + ((MODE == KC) ? K : nrows)) * 2));
-  o.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)up, 0, (int)bytes, 0x00020000);
-  o.kstride = (MODE == KC) ? 2u : (unsigned)(ld * 2);
-  o.c8 = 0;
-  return o;
-}
-template <int MODE>
-__device__ __forceinline__ void retarget_glds(Operand& o, long ld, int row0, int nrows, int wave, int lane, bool valid) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int piece = wave * 4 + p;
-    if (MODE == KC) {   // piece = 8 rows x 128 B; lane -> (row, physical chunk)
-      int row = piece * 8 + (lane >> 3), pc = lane & 7;
-      int c = pc ^ ((row >> 1) & 7);
-      int r = row0 + row;
-      if (p == 0) o.c8 = c * 8;                           // (c differs per piece only through the row swizzle; see stage_glds)
-      o.voff[p] = (valid && r < nrows) ? (unsigned)((r * ld + c * 8) * 2) : FC_OOB;
-    } else {            // piece = 4 k-rows x 256 B; lane -> (k row, physical 16-B chunk)
-      int k = piece * 4 + (lane >> 4), pc = lane & 15;
-      int sw = (((k >> 3) & 1) << 2) | (k & 3);
-      int c = (((pc >> 1) ^ sw) << 1) | (pc & 1);
-      int col = row0 + c * 8;
-      o.voff[p] = (valid && col < nrows) ? (unsigned)((k * ld + col) * 2) : FC_OOB;
-    }
-  }
-}
-// issue the 4 pieces of one operand tile for k-tile k0 into `buf` (16 KB)
-template <int MODE>
-__device__ __forceinline__ void stage_glds(const Operand& o, char* buf, int k0, int K, int wave, int lane) {
-  const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)k0 * o.kstride));
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    unsigned vo = o.voff[p];
-    if (MODE == KC) {  // k tail (K % 64 != 0): this lane's logical chunk within the tile
-      int row = (wave * 4 + p) * 8 + (lane >> 3);
-      int c = (lane & 7) ^ ((row >> 1) & 7);
-      vo = (k0 + c * 8 < K) ? vo : FC_OOB;
-    }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rsrc, (lds_ptr_t)(buf + (wave * 4 + p) * 1024), 16, vo, soff, 0, 0);
-  }
-}
 
 // 64-row epilogue image in ONE 32-KB staging buffer: rows of 128 floats, float4 slot s of row r stored at slot s ^ (r & 7)
 // (conflict-free for the accumulator writes -- 8 lanes, 8 rows, one column slot -- and for the row reads).
@@ -309,25 +180,6 @@ __device__ __forceinline__ void acc_to_lds_half(float* Cs, const f32x4 (&acc)[4]
     for (int j = 0; j < 4; ++j)
       *(float4*)(Cs + cs_slot(wm * 32 + ii * 16 + cl, wn * 16 + j * 4 + g)) =
           make_float4(acc[2 * HP + ii][j][0], acc[2 * HP + ii][j][1], acc[2 * HP + ii][j][2], acc[2 * HP + ii][j][3]);
-}
-// buffer descriptor for the epilogue stores: lanes outside the matrix use an out-of-range offset, so every thread issues the
-// SAME number of store instructions per tile and the main loop can use a counted s_waitcnt that skips them
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_store_rsrc(void* p, long bytes) {
-  unsigned long long base = (unsigned long long)p;
-  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-  void* up = (void*)(((unsigned long long)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(up, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
-}
-template <typename TC>
-__device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, size_t elem_off, bool ok, const float (&v)[8]) {
-  if (sizeof(TC) == 2) {
-    uint4 u = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
-    __builtin_amdgcn_raw_buffer_store_b128(*(v4u*)&u, r, ok ? (unsigned)(elem_off * 2) : FC_OOB, 0, 0);
-  } else {
-    float4 a = make_float4(v[0], v[1], v[2], v[3]), b = make_float4(v[4], v[5], v[6], v[7]);
-    __builtin_amdgcn_raw_buffer_store_b128(*(v4u*)&a, r, ok ? (unsigned)(elem_off * 4) : FC_OOB, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(*(v4u*)&b, r, ok ? (unsigned)(elem_off * 4 + 16) : FC_OOB, 0, 0);
-  }
 }
 // store instructions one thread issues per output tile with the compile-time epilogues (0: unknown -> full drain)
 template <int EPI, typename TC> struct EpiStores { static constexpr int n = EPI == EPI_GENERIC ? 0 : ((EPI == EPI_GELU || EPI == EPI_GELU_SG) ? 16 : 8) * (sizeof(TC) == 2 ? 1 : 2); };
@@ -516,6 +368,8 @@ __device__ __forceinline__ void tile_compute(const char* buf, f32x4 (&acc)[4][4]
     for (int i = 0; i < 4; ++i) af[i] = frag_read<AMODE>(la, wm * 64 + i * 16, ks, lane);
 #pragma unroll
     for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BMODE>(lb, wn * 64 + j * 16, ks, lane);
+    if (AMODE == KR) frag_fence(af);
+    if (BMODE == KR) frag_fence(bfr);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -551,10 +405,6 @@ __device__ __forceinline__ void gemm_mainloop(const bf16_t* __restrict__ A, long
   }
 }
 
-__device__ __forceinline__ int xcd_remap(int b, int nwg) {  // blocks b, b+8, ... share an XCD: give each XCD a contiguous id range
-  int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
 
 // Persistent single-problem kernel: the grid is at most 2 workgroups per CU and every workgroup walks the tiles
 // id, id + grid, id + 2*grid, ...  Operand tiles stream global -> LDS directly (LDS-DMA), double-buffered: the loads of
@@ -705,12 +555,6 @@ int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles,
   return 0;
 }
 
-static long long* g_stamps = nullptr;
-extern "C" int fc_dbg_read_stamps(long long* host, int n) {
-  if (!g_stamps) return -1;
-  (void)hipDeviceSynchronize();
-  return (int)hipMemcpy(host, g_stamps, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost);
-}
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int AM, int BMo, typename TC, int EPI>
@@ -766,7 +610,7 @@ static int launch_gemm(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, l
 
 int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K,
                  const GemmEpi& epi_in, hipStream_t s) {
-  { static const char* ab = getenv("FC_ABLATE"); if (ab && strstr(ab, "gemm")) return 0; }   // measurement aid (wrong results)
+  if (FC_ABLATED("gemm")) return 0;
   const GemmEpi& epi0 = epi_in;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   // vector-width constraints of this kernel; anything else goes to the generic path
@@ -778,17 +622,22 @@ int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm,
   if (epi0.preact && !aligned16(epi0.preact)) return 1;
   if (epi0.gelu_in && !aligned16(epi0.gelu_in)) return 1;
   if (epi0.pos && !aligned16(epi0.pos)) return 1;
+  // FC_GEMM_WS: 0 (default) tiled kernel only; 1 weight-stationary kernel wherever it applies (K = 384); 2 only for N >= 1024;
+  // 3 additionally only for M >= 8192.  Stand-alone the weight-stationary kernel is 18-23 % faster on the N = 1536 shapes, inside
+  // the four-stream client step (where 160-KB workgroups cannot share a CU with another stream's kernels) it is 0-4 % slower:
+  // DESIGN.md section 3.
+  static const int use_ws = getenv("FC_GEMM_WS") ? atoi(getenv("FC_GEMM_WS")) : 0;
+  if (use_ws && dtC == FC_BF16 && kind != FC_GEMM_TN && (use_ws == 1 || N >= 1024) && (use_ws < 3 || M >= 8192)) {   // K <= 384: weight-stationary kernel (fc_gemm_ws.hip)
+    int r = fc_gemm_ws(kind, A, lda, Bm, ldb, (bf16_t*)C, ldc, M, N, K, epi0, s);
+    if (r <= 0) return r;
+  }
   int tiles_n = fc_cdiv(N, BN);
   int tiles = fc_cdiv(M, BM) * tiles_n;
-  static int dbg = getenv("FC_GEMM_DBG") ? atoi(getenv("FC_GEMM_DBG")) : 0;
   GemmEpi epi = epi_in;
+#ifdef FC_PROBES
+  static const int dbg = getenv("FC_GEMM_DBG") ? atoi(getenv("FC_GEMM_DBG")) : 0;
   epi.dbg = dbg;
-  long long*& stamps = g_stamps;
-  if (getenv("FC_GEMM_STAMPS")) {
-    if (!stamps) { (void)hipMalloc(&stamps, 4096 * 32 * sizeof(long long)); }
-    (void)hipMemsetAsync(stamps, 0, 4096 * 32 * sizeof(long long), s);
-    epi.stamps = stamps;
-  }
+#endif
   if (kind == FC_GEMM_NT) {
     if (dtC == FC_BF16) return launch_gemm<KC, KC, bf16_t>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
     return launch_gemm<KC, KC, float>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);

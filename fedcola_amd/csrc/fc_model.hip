@@ -663,7 +663,7 @@ static int forward_impl(const fc_model* m, const float* params, const void* wc, 
     FC_TRY(fork_side(m, s));
     Ctx c2 = c;
     c2.s = m->side;
-    { static const char* ab = getenv("FC_ABLATE"); if (!(ab && strstr(ab, "txt"))) FC_TRY(tower_forward(c2, w, 1, nullptr, ids, feat_out, out_txt)); }   // (measurement aid)
+    if (!FC_ABLATED("txt")) FC_TRY(tower_forward(c2, w, 1, nullptr, ids, feat_out, out_txt));
     const int nmb = microbatches(m, B);
     if (nmb > 1) {
       const size_t ipx = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
@@ -746,8 +746,7 @@ static int flush_dw(const Ctx& c) {
     FC_CHECK_HIP(hipEventRecord(m->ev_dw_in2[k], m->mbs[k]));
     FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in2[k], 0));
   }
-  static const bool ablate_dw = getenv("FC_ABLATE_DW") != nullptr;   // measurement aid: skip the weight-gradient GEMMs (wrong results)
-  if (!ablate_dw) FC_TRY(fc_gemm_tn_grouped(st.dev + beg, (int)n, tiles, m->dws));
+  if (!FC_ABLATED("dw")) FC_TRY(fc_gemm_tn_grouped(st.dev + beg, (int)n, tiles, m->dws));
   st.flushed = all.size();
   return 0;
 }
@@ -888,7 +887,7 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     FC_TRY(fork_side(m, s));
     Ctx c2 = c;
     c2.s = m->side;
-    { static const char* ab = getenv("FC_ABLATE"); if (!(ab && strstr(ab, "txt"))) FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads)); }   // text tower (short) first: its dW chunks start early
+    if (!FC_ABLATED("txt")) FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads));   // text tower (short) first: its dW chunks start early
     const int nmb = c.defer ? microbatches(m, w.B) : 1;
     if (nmb > 1) {
       // image tower as micro-batch chains, interleaved layer by layer; the full-batch weight gradients of a layer are

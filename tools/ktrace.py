@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""Per-launch-group kernel durations from a rocprofv3 --kernel-trace csv directory: consecutive dispatches of one kernel
+(same name and grid) form a group (a micro-benchmark loop); prints the median / mean / min duration of each group.
+usage: tools/ktrace.py <dir> [min_group]"""
+import csv, glob, statistics, sys
+d = sys.argv[1]; min_group = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+groups = []
+for r in rows:
+    key = (r['Kernel_Name'], r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', ''))
+    dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    if groups and groups[-1][0] == key:
+        groups[-1][1].append(dur)
+    else:
+        groups.append((key, [dur]))
+for key, durs in groups:
+    if len(durs) < min_group:
+        continue
+    t = durs[3:] if len(durs) > 6 else durs
+    print(f"{key[0][:70]:70s} grid {key[1]:>7s} n={len(durs):3d} median {statistics.median(t):8.2f} us  mean {statistics.mean(t):8.2f}  min {min(t):8.2f}")
