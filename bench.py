@@ -2,29 +2,36 @@
 """bench.py -- img-txt pairs/sec of the FedCola client step (mome_small_patch16 = ViT-S image tower + same-width text
 tower, B=64, 224x224 RGB, 32-token captions, AdamW) on N MI355X GPUs, one federated client per GPU.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one iteration of FedavgClient.update's batch loop (zero_grad, forward, contrastive loss, backward, AdamW) on a
-synthetic Flickr30k-shaped batch already resident in HBM.  Clients are independent during local epochs (weak scaling);
-the timed region ends with one FedAvg aggregation (RCCL all-reduce of the pre-weighted flat parameter buffer).
-Prints ONE JSON line (rank 0).
+N > 1: one rank per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a rank; without
+it, `--gpus N` makes this process a launcher: it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+BEFORE touching the GPU itself, relays the child's output and exits with its code.
+
+A "step" is one iteration of FedavgClient.update's batch loop (zero_grad, forward, contrastive loss, backward, AdamW;
+/root/reference/src/client/fedavgclient.py:79-102) on a synthetic Flickr30k-shaped batch already resident in HBM.  Clients are
+independent during local epochs (weak scaling); the timed region ends with one FedAvg aggregation of the N clients
+(fedavgserver.py:591-668: host-computed closed-form weights, one HIP blend per rank, one RCCL all-reduce of the flat
+parameter buffer over xGMI).  Prints ONE JSON line (rank 0).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PAIR_GFLOP = 31.61           # algorithmic GEMM FLOPs per img-txt pair fwd+bwd, ViT-S, N_img=197, N_txt=32 (SURVEY.md 8d)
+STEP_ALG_GB = 10.8           # algorithmic HBM bytes per B=64 step, fully fused bf16 (SURVEY.md 8d)
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
 class Args:
@@ -34,6 +41,7 @@ class Args:
 
 
 def make_batch(B, seq, vocab, seed, device):
+    import torch
     g = torch.Generator().manual_seed(1000 + seed)
     img = (torch.randn(B, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1)
     ids = torch.randint(1, vocab, (B, seq), generator=g)
@@ -42,50 +50,87 @@ def make_batch(B, seq, vocab, seed, device):
     return img.to(device), ids.to(device)
 
 
-def gemm_roofline(steps=50):
-    """Dominant kernel: k_gemm_mfma (NT, fc1 shape M=12608 N=1536 K=384) timed with HIP events on its own stream."""
+def kernel_source_stamp():
+    """sha256 over the kernel sources: the PMC traffic figure in profiles/ is only valid for the sources it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fedcola_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# The dominant kernel of the step (profiles/: largest share of kernel time): the NN dX GEMM k_gemm_mfma<KC,KR,bf16,PLAIN>, at the
+# shape the model launches it with most FLOPs: dh2 = gdu . W1 of one image micro-batch chain (M = 32*197 rows, N = 384, K = 1536).
+ROOF_KIND, ROOF_M, ROOF_N, ROOF_K = 1, 32 * 197, 384, 1536
+
+
+def gemm_roofline(steps=200):
+    """Timed live with HIP events on the stream the kernel is launched on; launches are issued back to back from C (fc_k_gemm),
+    `steps` of them, so that the ~4 us host cost per launch is hidden behind the previous kernels."""
+    import torch
     from fedcola_amd import _lib
     L = _lib.lib()
-    M, N, K = 64 * 197, 1536, 384
+    M, N, K = ROOF_M, ROOF_N, ROOF_K
     A = torch.randn(M, K, device="cuda").bfloat16()
-    W = torch.randn(N, K, device="cuda").bfloat16()
+    W = torch.randn(K, N, device="cuda").bfloat16()
     Cm = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    bias = torch.randn(N, device="cuda")
     st = torch.cuda.Stream()
     sp = C.c_void_p(st.cuda_stream)
     P = _lib.ptr
     with torch.cuda.stream(st):
-        for _ in range(5):
-            _lib.check(L.fc_k_gemm(1, 0, 1, 1, P(A), P(W), P(Cm), M, N, K, P(bias), 0, sp))
+        for _ in range(10):
+            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(A), P(W), P(Cm), M, N, K, None, 0, sp))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
         for _ in range(steps):
-            _lib.check(L.fc_k_gemm(1, 0, 1, 1, P(A), P(W), P(Cm), M, N, K, P(bias), 0, sp))
+            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(A), P(W), P(Cm), M, N, K, None, 0, sp))
         e1.record(st)
     e1.synchronize()
     ms = e0.elapsed_time(e1) / steps
     flops = 2.0 * M * N * K
     achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "roofline_pmc.json")   # FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this launch
-    if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
     alg_bytes = 2.0 * (M * K + N * K + M * N)
-    return dict(bound="mfma", kernel="k_gemm_mfma<NT,bias> fc1 shape 12608x1536x384 bf16 (dominant kernel family of the step)",
-                achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
-                traffic=traffic, us_per_launch=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
-                algorithmic_bytes_per_launch=alg_bytes, hbm_frac=round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+    traffic, note = None, None
+    pmc = os.path.join(PROFILE_DIR, "roofline_pmc.json")      # FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch, tools/collect_profiles.sh
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("source_stamp") == kernel_source_stamp() and rec.get("shape") == [ROOF_KIND, M, N, K]:
+            traffic = rec.get("hbm_bytes_per_launch")
+        else:
+            note = "profiles/r02/roofline_pmc.json was measured on other kernel sources / another shape: traffic withheld (re-run tools/collect_profiles.sh)"
+    out = dict(bound="mfma", kernel=f"k_gemm_mfma<KC,KR,bf16,PLAIN> (NN dX GEMM: dh2 = gdu.W1 of one image micro-batch chain) {M}x{N}x{K} bf16",
+               achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
+               traffic=traffic, us_per_launch=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
+               algorithmic_bytes_per_launch=alg_bytes, hbm_frac=round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+    if note:
+        out["traffic_note"] = note
+    return out
 
 
-def cpu_baseline_child(B, seq, vocab, steps):
-    """Runs in a CHILD process (no GPU touched): the oracle's explicit fp32 client step on the host cores."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
+    """Runs in a CHILD process (no GPU touched): the oracle's explicit fp32 client step on the host cores.
+    Protocol: fixed thread count = min(logical CPUs, 32) (torch's CPU GEMMs at these sizes stop scaling
+    there, and a fixed policy keeps runs comparable), `warm` warm-up steps, then `timed` steps -- cut short only by the time budget."""
+    import torch
     from oracle import mome_oracle as O
     from fedcola_amd.mome import create_model
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
-    threads = max(1, min(cores, 64))          # torch CPU GEMMs stop scaling (and spin-wait badly) far below 256 threads
+    threads = max(1, min(cores, 32))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     a = Args()
@@ -95,31 +140,27 @@ def cpu_baseline_child(B, seq, vocab, steps):
     cfg = O.OracleCfg(D=384, depth=12, heads=6, vocab=vocab, max_text_len=seq)
     img, ids = make_batch(B, seq, vocab, 0, "cpu")
     state = dict(step=0, m={}, v={})
-    O.client_step(p, cfg, ("img+txt", img, ids), state, lr=1e-4)     # warm-up
-    best = None
-    for th in sorted({t for t in (16, 32, 64) if t <= max(16, threads)}):   # torch CPU GEMMs at these sizes do not scale to every core
-        torch.set_num_threads(th)
+    t_start = time.perf_counter()
+    for _ in range(warm):
+        O.client_step(p, cfg, ("img+txt", img, ids), state, lr=1e-4)
+    times = []
+    for _ in range(timed):
         t0 = time.perf_counter()
         O.client_step(p, cfg, ("img+txt", img, ids), state, lr=1e-4)
-        d = time.perf_counter() - t0
-        if best is None or d < best[0]:
-            best = (d, th)
-    threads = best[1]
-    torch.set_num_threads(threads)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        O.client_step(p, cfg, ("img+txt", img, ids), state, lr=1e-4)
-    dt = (time.perf_counter() - t0) / steps
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s and len(times) >= 5:
+            break
+    dt = sum(times) / len(times)
     print(json.dumps(dict(value=round(B / dt, 2), unit="img-txt pairs/s", cores=threads, kind="port",
-                          sample=f"{steps} timed + 1 warm-up fp32 steps of the same B={B} ViT-S workload by oracle/mome_oracle.py "
-                                 f"(torch CPU ops, {threads} threads; host reports {os.cpu_count()} logical CPUs)")), flush=True)
+                          sample=f"{len(times)} timed + {warm} warm-up fp32 steps of the same B={B} ViT-S workload by oracle/mome_oracle.py "
+                                 f"(torch {torch.__version__} CPU ops, {threads} threads, {dt:.2f} s/step; host: {cpu_model_name()}, "
+                                 f"{os.cpu_count()} logical CPUs)")), flush=True)
 
 
-def cpu_baseline(B, seq, vocab, steps=2, timeout=240):
+def cpu_baseline(B, seq, vocab, timeout=420):
     """Bounded CPU baseline in a child process started BEFORE this process touches the GPU."""
-    import subprocess
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--batch", str(B), "--steps", str(steps)],
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--batch", str(B)],
                              capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         return json.loads(line[-1]) if line else dict(value=None, unit="img-txt pairs/s", kind="port", sample="child failed: " + out.stderr[-300:])
@@ -127,37 +168,77 @@ def cpu_baseline(B, seq, vocab, steps=2, timeout=240):
         return dict(value=None, unit="img-txt pairs/s", kind="port", cores=None, sample=f"CPU baseline exceeded {timeout}s and was skipped")
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """`--gpus N` without a torchrun environment: start the N ranks as a child job (this process has not touched the GPU)."""
+    import torch
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < a.gpus and not os.environ.get("FC_BENCH_ONE_DEVICE"):
+        print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible (set FC_BENCH_ONE_DEVICE=1 to validate the multi-rank path on one "
+              f"device)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dropout-line", action="store_true")
+    ap.add_argument("--agg", default="torch", choices=["torch", "cabi"], help="cross-rank sum of the aggregation: torch.distributed.all_reduce "
+                    "(RCCL) or the C ABI's own RCCL communicator (fc_comm_* / fc_aggregate)")
     ap.add_argument("--h2d", action="store_true", help="non-default: batches start in pinned host memory and reach the GPU through "
                     "fedcola_amd.loaders.DevicePrefetcher (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--fedprox-mu", type=float, default=0.0, help="non-default workload: FedproxClient step (proximal term, row N3)")
+    ap.add_argument("--dropout", type=float, default=0.0, help="drop-path rate of the headline line (reference default 0.1 is the second line)")
+    ap.add_argument("--dump-agg", default=None, help="directory: every rank saves its client's weights before the aggregation and rank 0 the "
+                    "global model before / after it (tests/test_gpu_bench.py)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_child:
-        cpu_baseline_child(a.batch, Args.seq_len, Args.vocab_size, min(a.steps, 3))
-        return
+        cpu_baseline_child(a.batch, Args.seq_len, Args.vocab_size, warm=3, timed=10, budget_s=300)
+        return 0
+    in_job = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not in_job:
+        return launch_ranks(a, sys.argv[1:])
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if in_job and world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
     cpu_base = None
     if world == 1 and not a.no_cpu_baseline:
         cpu_base = cpu_baseline(a.batch, Args.seq_len, Args.vocab_size)      # before any GPU call in this process
-    if os.environ.get("FC_BENCH_ONE_DEVICE"):      # validation of the N>1 code path on a 1-GPU box: every rank on cuda:0
+    import torch
+    one_device = bool(os.environ.get("FC_BENCH_ONE_DEVICE"))      # validation of the N>1 code path on a 1-GPU box: every rank on cuda:0
+    if one_device:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("FC_BENCH_BACKEND", "nccl")               # "nccl" is RCCL on ROCm
+        backend = os.environ.get("FC_BENCH_BACKEND", "gloo" if one_device else "nccl")       # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -166,6 +247,7 @@ def main():
     from fedcola_amd.mome import create_model
     args = Args()
     args.precision = a.precision
+    args.dropout = a.dropout
     torch.manual_seed(1 + rank)
     model = create_model("mome_small_patch16", False, args=args, num_classes=[None, None], modalities=["img", "txt"],
                          tasks=["rtv", "rtv"]).to(dev)
@@ -195,33 +277,54 @@ def main():
                 yield himg, hids
         feed = iter(DevicePrefetcher(host_batches(), dev, depth=2, stream=model.side_stream()))
 
-    def step():
+    dp_gen = torch.Generator(device=dev)
+    dp_gen.manual_seed(77 + rank)
+
+    def step(drop_model=None):
         nonlocal img, ids
         if feed is not None:
             img, ids = next(feed)
         step_no[0] += 1
-        args = (model._handle.h, P(model.flat), P(grads), P(m1), P(m2), P(model._wc_or_flat()), P(img), P(ids), None,
-                B, seq, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, step_no[0], P(lossbuf), P(ws), ws.numel(), sp)
+        mdl = drop_model or model
+        dp = mdl.make_droppath(B, generator=dp_gen)       # None at rate 0; else timm DropPath multipliers drawn on the device
+        cargs = (model._handle.h, P(model.flat), P(grads), P(m1), P(m2), P(model._wc_or_flat()), P(img), P(ids), None,
+                 B, seq, P(dp), 1e-4, 0.9, 0.999, 1e-8, 0.0, step_no[0], P(lossbuf), P(ws), ws.numel(), sp)
         if a.fedprox_mu > 0:
-            _lib.check(L.fc_client_step_prox(*args, P(gflat), a.fedprox_mu, P(pscr), pscr.numel()))
+            _lib.check(L.fc_client_step_prox(*cargs, P(gflat), a.fedprox_mu, P(pscr), pscr.numel()))
         else:
-            _lib.check(L.fc_client_step(*args))
+            _lib.check(L.fc_client_step(*cargs))
+        return dp
 
     # FedAvg aggregation of the `world` concurrent clients through the product path (fedcola_amd/aggregate.py): host-computed
     # coefficient table + closed-form weights -> one HIP blend kernel per rank -> one RCCL all-reduce over xGMI
-    plan = None
+    plan = comm = None
     if world > 1:
         from fedcola_amd import aggregate as agg
         import copy
         cids = list(range(world))                                          # one client per rank
         keys = list(model.required_params().keys())
-        coef = {k: {i: 1.0 / world for i in cids} for k in keys}           # equal client sizes, scope 'dataset'
+        sizes = {i: 1280 for i in cids}                                    # equal client sizes, scope 'dataset'
+        coef = {k: {i: sizes[i] / sum(sizes.values()) for i in cids} for k in keys}
         plan = agg.build_plan(model, cids, coef, {i: model.segments for i in cids})
-        global_model = copy.deepcopy(model)
+        torch.manual_seed(1)                                               # the global model is identical on every rank
+        global_model = create_model("mome_small_patch16", False, args=args, num_classes=[None, None], modalities=["img", "txt"],
+                                    tasks=["rtv", "rtv"]).to(dev)
+        if a.agg == "cabi":
+            from fedcola_amd.comm import Comm
+            comm = Comm.from_torch_dist()
 
-    def aggregate():
+    def aggregate(dump=None):
         if world > 1:
-            agg.aggregate(global_model, plan, {rank: model.flat.data}, rank=rank, world=world)
+            if dump:
+                os.makedirs(dump, exist_ok=True)
+                torch.save(model.flat.detach().cpu(), os.path.join(dump, f"client{rank}.pt"))
+                if rank == 0:
+                    torch.save(global_model.flat.detach().cpu(), os.path.join(dump, "global_before.pt"))
+            agg.aggregate(global_model, plan, {rank: model.flat.data}, rank=rank, world=world, comm=comm)
+            if dump and rank == 0:
+                torch.save(global_model.flat.detach().cpu(), os.path.join(dump, "global_after.pt"))
+                json.dump(dict(keys=keys, coef={k: [coef[k][i] for i in cids] for k in keys}, segments={k: [s["offset"], s["numel"]] for k, s in model.segments.items()}),
+                          open(os.path.join(dump, "plan.json"), "w"))
             model.flat.data.copy_(global_model.flat.data)                  # next round's download(): device-to-device
             model._bump()
             model.prepare_weights(force=True)                              # ... and its bf16 compute weights
@@ -239,33 +342,71 @@ def main():
     for _ in range(a.steps):
         step()
     t_enq = time.perf_counter() - t0        # host time to enqueue the steps (launch-bound if close to dt)
-    aggregate()
+    torch.cuda.synchronize()
+    t_steps = time.perf_counter() - t0
+    aggregate(a.dump_agg)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = [dt]
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        t = torch.tensor([dt, t_steps], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g[0]) for g in gathered]
+        dt = max(per_rank)
+        t_steps = max(float(g[1]) for g in gathered)
     loss = float(lossbuf[1])
+
+    # second throughput line: the reference's default --dropout 0.1 (timm DropPath, mome.py:213,223,726-728), fewer steps, same protocol
+    drop_line = None
+    if rank == 0 and world == 1 and not a.no_dropout_line and a.dropout == 0.0 and not a.h2d and a.fedprox_mu == 0:
+        a2 = Args()
+        a2.precision, a2.dropout = a.precision, 0.1
+        dm = create_model("mome_small_patch16", False, args=a2, num_classes=[None, None], modalities=["img", "txt"], tasks=["rtv", "rtv"])
+        dm.flat.data = model.flat.data          # only its drop-path table is used (make_droppath)
+        dm.train()
+        k2 = max(10, a.steps // 4)
+        for _ in range(5):
+            step(dm)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step(dm)
+        torch.cuda.synchronize()
+        d2 = time.perf_counter() - t1
+        drop_line = dict(value=round(B * k2 / d2, 1), unit="img-txt pairs/s", ms_per_step=round(d2 / k2 * 1e3, 3), steps=k2, drop_path_rate=0.1,
+                         note="reference default --dropout 0.1: per-sample DropPath multipliers drawn on the device every step")
+
     if rank == 0:
         pairs = world * B * a.steps / dt
         out = dict(metric="img-txt pairs/sec per client round (ViT-S+BERT-mini)", value=round(pairs, 1), unit="img-txt pairs/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype=a.precision, data="synthetic",
                    config=dict(workload="Flickr30k FedCola, 1 img-txt client per GPU, mome_small_patch16 (ViT-S + 12x384 text tower), "
-                                        f"B={B}, 224x224 RGB, {seq}-token captions, vocab 7732, AdamW lr 1e-4, drop-path 0"
+                                        f"B={B}, 224x224 RGB, {seq}-token captions, vocab 7732, AdamW lr 1e-4, drop-path {a.dropout:g}"
                                         + (f", FedProx mu={a.fedprox_mu}" if a.fedprox_mu > 0 else "")
                                         + (", batches from host memory through the device prefetcher" if a.h2d else ""),
                                global_batch=world * B, parallelism=f"{world} concurrent clients + RCCL FedAvg all-reduce"),
-                   step_mfma_frac=round(pairs * PAIR_GFLOP / 1e3 / (world * PEAK_BF16_TFLOPS), 4), last_loss=round(loss, 4), enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
+                   step_mfma_frac=round(pairs * PAIR_GFLOP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
+                   step_hbm_frac=round(STEP_ALG_GB * (pairs / (world * B)) / PEAK_HBM_GBS, 4),
+                   last_loss=round(loss, 4), enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3),
+                   aggregate_ms=round((dt - t_steps) * 1e3, 3), allreduce_bytes=(4 * n if world > 1 else 0),
+                   per_rank_ms_per_step=[round(x / a.steps * 1e3, 3) for x in per_rank],
+                   aggregate_path=("none (1 client)" if world == 1 else ("C ABI fc_aggregate: HIP blend + ncclAllReduce" if comm is not None else
+                                   "HIP blend + torch.distributed.all_reduce (" + dist.get_backend() + ")")))
+        if drop_line is not None:
+            out["dropout_0p1"] = drop_line
         if not a.no_roofline:
             out["roofline"] = gemm_roofline()
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -75,6 +75,16 @@ SIGNATURES = {
     "fc_prox_scratch_bytes": (C.c_size_t, [_P]),
     "fc_prox_term": (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P, _Z, _P]),
     "fc_aggregate_blend": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "fc_comm_unique_id": (C.c_int, [_P, _Z]),
+    "fc_comm_create": (C.c_int, [_P, _Z, _I, _I, C.POINTER(_P)]),
+    "fc_comm_destroy": (None, [_P]),
+    "fc_comm_rank": (_I, [_P]),
+    "fc_comm_world": (_I, [_P]),
+    "fc_allreduce_sum": (C.c_int, [_P, _P, _L, _P]),
+    "fc_aggregate": (C.c_int, [_P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "fc_aggregate_partial": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "fc_aggregate_blend_seq": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "fc_aggregate_exact": (C.c_int, [_P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _P]),
     "fc_copy_outputs": (C.c_int, [_P, _P, _Z, _P, _P, _P]),
     "fc_scale_segments": (C.c_int, [_P, _P, _P, _P, _I, _P]),
     "fc_upload_fold": (C.c_int, [_P, _P, _P, _P]),

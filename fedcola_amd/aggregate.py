@@ -13,6 +13,7 @@ with the new global model in HBM, so next round's ``download`` is a device-to-de
 """
 from __future__ import annotations
 
+import ctypes as C
 import re
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Mapping, Optional, Sequence
@@ -154,29 +155,75 @@ def build_plan(global_model, ids: Sequence[int], coefficients, client_segments: 
     return BlendPlan(keys, list(ids), seg_off, seg_len, src_off, weights)
 
 
-def hip_local_partial(plan: BlendPlan, global_flat: torch.Tensor, local_flats: Mapping[int, torch.Tensor], include_global: bool) -> torch.Tensor:
+def _device_tables(plan: BlendPlan, dev, local_ids, include_global: bool):
+    """The plan's tables on `dev`, masked for the clients this rank holds: built once per (device, local set) and kept on the plan
+    (the plan of a round is reused for every global model's all-reduce; bench.py reuses one plan for all rounds)."""
+    cache = plan.__dict__.setdefault("_dev", {})
+    key = (str(dev), tuple(sorted(local_ids)), bool(include_global))
+    t = cache.get(key)
+    if t is None:
+        w = plan.weights.clone()
+        src = plan.src_off.clone()
+        for j, i in enumerate(plan.ids):
+            if i not in local_ids:
+                w[:, 1 + j] = 0.0
+                src[:, j] = -1
+        if not include_global:
+            w[:, 0] = 0.0
+        runs = _copy_runs(plan)
+        t = dict(seg_off=plan.seg_off.to(dev), seg_len=plan.seg_len.to(dev), src=src.contiguous().to(dev), w=w.contiguous().to(dev),
+                 run_off=(C.c_int64 * len(runs))(*[o for o, _ in runs]), run_len=(C.c_int64 * len(runs))(*[e - o for o, e in runs]),
+                 n_runs=len(runs))
+        cache[key] = t
+    return t
+
+
+def _bases_array(plan: BlendPlan, local_flats):
+    m = len(plan.ids)
+    arr = (C.c_void_p * max(m, 1))()
+    for j, i in enumerate(plan.ids):
+        arr[j] = local_flats[i].data_ptr() if i in local_flats else None
+    return arr
+
+
+def _partial_buffer(global_model):
+    """numel-float scratch kept on the model (zero once: ranges outside the plan stay zero through every all-reduce)."""
+    g = global_model.flat.data
+    p = getattr(global_model, "_agg_partial", None)
+    if p is None or p.device != g.device or p.numel() != g.numel():
+        p = torch.zeros_like(g)
+        global_model._agg_partial = p
+    return p
+
+
+def hip_local_partial(plan: BlendPlan, global_flat: torch.Tensor, local_flats: Mapping[int, torch.Tensor], include_global: bool,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """This rank's share of the blend with one HIP kernel: [w_g*g if include_global] + sum_{local j} w_j*theta_j, laid out like
-    the global flat buffer (zeros outside the plan's segments)."""
+    the global flat buffer (zeros outside the plan's segments).  No host synchronisation: the tables are cached on the plan and
+    the client pointers travel as kernel arguments."""
+    from . import _lib
+    from ._lib import check, ptr
+    if len(plan.ids) > 64:
+        return _hip_local_partial_many(plan, global_flat, local_flats, include_global)
+    t = _device_tables(plan, global_flat.device, set(local_flats.keys()), include_global)
+    if out is None:
+        out = torch.zeros_like(global_flat)
+    check(_lib.lib().fc_aggregate_partial(ptr(out), ptr(global_flat), _bases_array(plan, local_flats), len(plan.ids), ptr(t["seg_off"]),
+                                          ptr(t["seg_len"]), ptr(t["src"]), ptr(t["w"]), len(plan.keys), _lib.stream_ptr()))
+    return out
+
+
+def _hip_local_partial_many(plan, global_flat, local_flats, include_global):
+    """More than 64 sampled clients: the client pointers go through a device table (fc_aggregate_blend)."""
     from . import _lib
     from ._lib import check, ptr
     dev = global_flat.device
-    m = len(plan.ids)
-    w = plan.weights.clone()
-    src = plan.src_off.clone()
-    bases = torch.zeros(m, dtype=torch.int64)
-    for j, i in enumerate(plan.ids):
-        if i in local_flats:
-            bases[j] = local_flats[i].data_ptr()
-        else:
-            w[:, 1 + j] = 0.0
-            src[:, j] = -1
-    if not include_global:
-        w[:, 0] = 0.0
+    t = _device_tables(plan, dev, set(local_flats.keys()), include_global)
+    bases = torch.tensor([local_flats[i].data_ptr() if i in local_flats else 0 for i in plan.ids], dtype=torch.int64).to(dev)
     out = torch.zeros_like(global_flat)
-    d = [t.to(dev) for t in (bases, plan.seg_off, plan.seg_len, src.contiguous(), w.contiguous())]
-    check(_lib.lib().fc_aggregate_blend(ptr(out), ptr(global_flat), ptr(d[0]), m, ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]),
-                                        len(plan.keys), _lib.stream_ptr()))
-    torch.cuda.current_stream().synchronize()          # the tables above are temporaries
+    check(_lib.lib().fc_aggregate_blend(ptr(out), ptr(global_flat), ptr(bases), len(plan.ids), ptr(t["seg_off"]), ptr(t["seg_len"]), ptr(t["src"]),
+                                        ptr(t["w"]), len(plan.keys), _lib.stream_ptr()))
+    torch.cuda.current_stream().synchronize()          # `bases` is a temporary
     return out
 
 
@@ -197,11 +244,26 @@ def _copy_runs(plan: BlendPlan):
 
 
 def aggregate(global_model, plan: BlendPlan, local_flats: Mapping[int, torch.Tensor], *, rank: int = 0, world: int = 1,
-              all_reduce: Optional[Callable[[torch.Tensor], None]] = None, local_partial=hip_local_partial):
-    """Blend into ``global_model`` in place.  With world > 1 every rank contributes the clients it trained and the
-    partials are summed by ``all_reduce`` (torch.distributed.all_reduce over RCCL by default)."""
+              all_reduce: Optional[Callable[[torch.Tensor], None]] = None, local_partial=None, comm=None):
+    """Blend into ``global_model`` in place.  With world > 1 every rank contributes the clients it trained and the partials are
+    summed over the ranks: through the C ABI's own RCCL communicator when ``comm`` (fedcola_amd.comm.Comm) is given
+    (``fc_aggregate``: blend + ncclAllReduce + copy-back in one call), else by ``all_reduce`` (torch.distributed.all_reduce over RCCL
+    by default).  ``local_partial`` replaces the HIP blend (CPU tests)."""
     g = global_model.flat.data
-    partial = local_partial(plan, g, local_flats, include_global=(rank == 0))
+    if local_partial is None and g.is_cuda and len(plan.ids) <= 64 and (world == 1 or comm is not None):
+        from . import _lib
+        from ._lib import check, ptr
+        t = _device_tables(plan, g.device, set(local_flats.keys()), rank == 0)
+        partial = _partial_buffer(global_model) if world > 1 else g
+        check(_lib.lib().fc_aggregate(comm.h if (comm is not None and world > 1) else None, ptr(g), ptr(partial), g.numel(),
+                                      _bases_array(plan, local_flats), len(plan.ids), ptr(t["seg_off"]), ptr(t["seg_len"]), ptr(t["src"]),
+                                      ptr(t["w"]), len(plan.keys), t["run_off"], t["run_len"], t["n_runs"], _lib.stream_ptr()))
+        global_model._bump()
+        return global_model
+    if local_partial is None:
+        partial = hip_local_partial(plan, g, local_flats, include_global=(rank == 0), out=_partial_buffer(global_model) if world > 1 else None)
+    else:
+        partial = local_partial(plan, g, local_flats, include_global=(rank == 0))
     if world > 1:
         if all_reduce is None:
             import torch.distributed as dist
@@ -209,5 +271,46 @@ def aggregate(global_model, plan: BlendPlan, local_flats: Mapping[int, torch.Ten
         all_reduce(partial)
     for o, e in _copy_runs(plan):                        # only the planned (required_params) segments are replaced
         g[o:e].copy_(partial[o:e])
+    global_model._bump()
+    return global_model
+
+
+def aggregate_exact(global_model, plan_keys: Sequence[str], ids: Sequence[int], coefficients, client_segments, local_flats, *, comm=None):
+    """The reference's sequential in-place blend itself, in its order and rounding (``fc_aggregate_blend_seq`` /
+    ``fc_aggregate_exact``): bit-identical to fedavgserver.py:656-664 in fp32.  Verification mode of the closed form.
+    Single process: every sampled client is local.  With ``comm``: one client per rank, ids[r] trained on rank r; the client buffers
+    are all-gathered (padded to the longest) and blended in rank (= ascending id) order on every rank."""
+    from . import _lib
+    from ._lib import check, ptr
+    g = global_model.flat.data
+    dev = g.device
+    m = len(ids)
+    gseg = global_model.segments
+    seg_off = torch.tensor([gseg[k]["offset"] for k in plan_keys], dtype=torch.int64)
+    seg_len = torch.tensor([gseg[k]["numel"] for k in plan_keys], dtype=torch.int64)
+    src = torch.full((len(plan_keys), m), -1, dtype=torch.int64)
+    coef = torch.zeros(len(plan_keys), m, dtype=torch.float32)
+    for s, k in enumerate(plan_keys):
+        for j, i in enumerate(ids):
+            if k in client_segments[i] and coefficients[k][i] != 0:
+                src[s, j] = client_segments[i][k]["offset"]
+                coef[s, j] = coefficients[k][i]
+    d = [t.to(dev) for t in (seg_off, seg_len, src.contiguous(), coef.contiguous())]
+    L = _lib.lib()
+    if comm is None or comm.world == 1:
+        assert all(i in local_flats for i in ids), "single-process exact blend needs every sampled client's weights"
+        arr = (C.c_void_p * max(m, 1))(*[local_flats[i].data_ptr() for i in ids])
+        check(L.fc_aggregate_blend_seq(ptr(g), arr, m, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), len(plan_keys), _lib.stream_ptr()))
+    else:
+        assert m == comm.world and len(local_flats) == 1, "exact mode across ranks: one client per rank"
+        (mine, flat), = local_flats.items()
+        assert ids[comm.rank] == mine
+        slot = max(max(int(sg["offset"]) + int(sg["numel"]) for sg in client_segments[i].values()) for i in ids)
+        local = torch.zeros(slot, device=dev)
+        local[: min(slot, flat.numel())].copy_(flat[: min(slot, flat.numel())])
+        gathered = torch.empty(slot * comm.world, device=dev)
+        check(L.fc_aggregate_exact(comm.h, ptr(g), ptr(local), ptr(gathered), slot, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), len(plan_keys),
+                                   _lib.stream_ptr()))
+    torch.cuda.current_stream().synchronize()            # the tables above are temporaries of this (verification) call
     global_model._bump()
     return global_model

@@ -1,0 +1,74 @@
+"""RCCL communicator of the C ABI (``fc_comm_*`` in include/fedcola_hip.h): one rank per process / GPU.
+
+The unique id has to reach every rank by some side channel; ``Comm.from_torch_dist`` uses the already-initialised
+``torch.distributed`` group for that (any backend -- the id is 128 bytes), ``Comm.from_file`` a shared file.  A non-PyTorch caller
+does the same with its own transport.  Reference: the single-process gather of client state_dicts at
+/root/reference/src/server/fedavgserver.py:566-589 and the aggregation call at :812-819."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+from . import _lib
+from ._lib import check
+
+ID_BYTES = 128
+
+
+class Comm:
+    def __init__(self, handle, rank, world):
+        self.h, self.rank, self.world = handle, rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(ID_BYTES)
+        check(_lib.lib().fc_comm_unique_id(buf, ID_BYTES))
+        return buf.raw
+
+    @classmethod
+    def create(cls, uid: bytes, rank: int, world: int) -> "Comm":
+        h = C.c_void_p()
+        buf = C.create_string_buffer(uid, ID_BYTES)
+        check(_lib.lib().fc_comm_create(buf, ID_BYTES, rank, world, C.byref(h)))
+        return cls(h, rank, world)
+
+    @classmethod
+    def from_torch_dist(cls) -> "Comm":
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls.create(box[0], rank, world)
+
+    @classmethod
+    def from_file(cls, path: str, rank: int, world: int, timeout: float = 120.0) -> "Comm":
+        if rank == 0:
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(cls.unique_id())
+            os.replace(tmp, path)
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"no RCCL id at {path}")
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            uid = f.read()
+        return cls.create(uid, rank, world)
+
+    def all_reduce(self, t):
+        import torch
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        check(_lib.lib().fc_allreduce_sum(self.h, _lib.ptr(t), t.numel(), _lib.stream_ptr()))
+
+    def close(self):
+        if self.h:
+            _lib.lib().fc_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

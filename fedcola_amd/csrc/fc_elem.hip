@@ -683,7 +683,11 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_reparam_fold(const float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ sc,
                                                       T* __restrict__ dst, size_t n) {
   float s = sc[0];
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) Io<T>::st(dst, i, W[i] + s * A[i]);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+#pragma clang fp contract(off)      // the reference rounds the product, then the sum (fedavgclient.py:176): no fma, so that the upload is bit-identical
+    const float t = s * A[i];
+    Io<T>::st(dst, i, W[i] + t);
+  }
 }
 int fc_reparam_fold(int dt, const float* W, const float* A, const float* scale, void* dst, size_t n, hipStream_t s) {
   int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);

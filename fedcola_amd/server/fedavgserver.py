@@ -207,9 +207,11 @@ class FedavgServer(BaseServer):
         drop_aux = self.args.with_aux and client.modality != "img+txt"
         return {k: s for k, s in model.segments.items() if not (drop_aux and ("aux" in k or "cross_modal_scale" in k))}
 
-    def _aggregate(self, ids, updated_sizes, fedavg=False, local_partial=None, all_reduce=None):
+    def _aggregate(self, ids, updated_sizes, fedavg=False, local_partial=None, all_reduce=None, exact=False):
         """fedavgserver.py:591-668 with the same inputs (self.global_model / task / modality / dataset / out_modality_scale /
-        param_scope / clients)."""
+        param_scope / clients).  ``self.comm`` (fedcola_amd.comm.Comm, optional) routes the cross-rank sum through the C ABI's own
+        RCCL communicator instead of torch.distributed.  ``exact=True``: the reference's sequential loop itself on the device
+        (bit-identical rounding; verification mode -- every sampled client local, or one client per rank with ``self.comm``)."""
         assert set(updated_sizes.keys()) == set(ids)
         keys = list(self.global_model.required_params().keys())
         coefficients = agg.mixing_coefficients(keys, self.param_scope, updated_sizes, self.clients, dataset=self.dataset, task=self.task,
@@ -225,8 +227,12 @@ class FedavgServer(BaseServer):
                 continue                                                      # trained on another rank
             up = c.upload()                                                   # folds aux into the weights when needed
             local_flats[i] = getattr(c, "_folded", None) if (self.args.with_aux and c.modality != "img+txt") else c.model.flat.data
+        comm = getattr(self, "comm", None)
+        if exact:
+            agg.aggregate_exact(self.global_model, keys, ids, coefficients, client_segments, local_flats, comm=comm)
+            return
         kw = {} if local_partial is None else {"local_partial": local_partial}
-        agg.aggregate(self.global_model, plan, local_flats, rank=rank, world=world, all_reduce=all_reduce, **kw)
+        agg.aggregate(self.global_model, plan, local_flats, rank=rank, world=world, all_reduce=all_reduce, comm=comm, **kw)
 
     def _empty_client_models(self):
         for client in self.clients:

@@ -156,6 +156,47 @@ int fc_cream_combine(const float* const* vecs_dev, const float* w, int32_t C, in
 int fc_aggregate_blend(float* out, const float* global, const float* const* client_bases, int32_t n_clients,
                        const int64_t* seg_offset, const int64_t* seg_numel, const int64_t* src_offset, const float* seg_weights,
                        int32_t n_segments, void* stream);
+
+/* ---- aggregation across processes (one rank per GPU) without PyTorch: an RCCL communicator behind an opaque handle.
+ * Replaces the reference's single-process gather of client state_dicts into `self.global_model` (fedavgserver.py:566-589,
+ * 812-819).  librccl.so is bound at run time (dlopen); single-process callers never need it.
+ * fc_comm_unique_id: rank 0 fills a FC_COMM_ID_BYTES blob (ncclGetUniqueId) and hands it to every rank by its own means
+ * (file, socket, MPI, torch.distributed.broadcast_object_list ...); fc_comm_create is collective over the ranks. */
+#define FC_COMM_ID_BYTES 128
+typedef struct fc_comm fc_comm_t;
+int fc_comm_unique_id(void* id_out, size_t bytes);
+int fc_comm_create(const void* id, size_t bytes, int32_t rank, int32_t world, fc_comm_t** out);
+void fc_comm_destroy(fc_comm_t* comm);
+int32_t fc_comm_rank(const fc_comm_t* comm);
+int32_t fc_comm_world(const fc_comm_t* comm);
+/* in-place sum over the ranks of a device buffer (ncclAllReduce over xGMI); no-op for comm == NULL / world 1 */
+int fc_allreduce_sum(fc_comm_t* comm, float* buf, int64_t n, void* stream);
+/* FedavgServer._aggregate (fedavgserver.py:591-668) for one global model, closed form:
+ *   partial = [seg_weights[s][0] * global] + sum_j seg_weights[s][1+j] * client_bases[j][src_offset[s][j] ...]   (as fc_aggregate_blend)
+ *   partial <- all-reduce(sum) over the ranks;   global[run] <- partial[run] for the planned ranges.
+ * Each rank passes the clients it trained (weights of the others zero, src_offset < 0) and only rank 0 a non-zero global
+ * weight, so the sum is the reference's blend.  client_bases is a HOST array of n_clients (<= 64) device pointers;
+ * run_offset / run_numel are HOST arrays; the segment tables are device memory; partial is a numel-float device scratch.
+ * comm == NULL or world 1: blends straight into `global` (no scratch traffic, no copy). */
+int fc_aggregate(fc_comm_t* comm, float* global, float* partial, int64_t numel, const float* const* client_bases, int32_t n_clients,
+                 const int64_t* seg_offset, const int64_t* seg_numel, const int64_t* src_offset, const float* seg_weights,
+                 int32_t n_segments, const int64_t* run_offset, const int64_t* run_numel, int32_t n_runs, void* stream);
+/* the blend step of fc_aggregate alone (same arguments; `out` may be `global`): for callers that run the all-reduce themselves,
+ * e.g. torch.distributed.all_reduce over RCCL */
+int fc_aggregate_partial(float* out, const float* global, const float* const* client_bases, int32_t n_clients,
+                         const int64_t* seg_offset, const int64_t* seg_numel, const int64_t* src_offset, const float* seg_weights,
+                         int32_t n_segments, void* stream);
+/* The reference's loop itself, in its order and rounding: for j ascending, global <- global + fl32((client_j - global) * coef[s][j])
+ * (fedavgserver.py:656-664; no fused multiply-add), skipping coef == 0 / src_offset < 0.  Bit-identical to the reference's fp32
+ * result; used as the verification mode of the closed form.  client_bases: HOST array of device pointers (<= 64). */
+int fc_aggregate_blend_seq(float* global, const float* const* client_bases, int32_t n_clients, const int64_t* seg_offset,
+                           const int64_t* seg_numel, const int64_t* src_offset, const float* coef, int32_t n_segments, void* stream);
+/* exact-order aggregation across ranks (one client per rank, ascending client id = rank order): ncclAllGather of every rank's
+ * client buffer (slot_numel floats each, padded) into `gathered` [world * slot_numel], then fc_aggregate_blend_seq over the
+ * slots.  src_offset / coef are [n_segments, world]. */
+int fc_aggregate_exact(fc_comm_t* comm, float* global, const float* local_client, float* gathered, int64_t slot_numel,
+                       const int64_t* seg_offset, const int64_t* seg_numel, const int64_t* src_offset, const float* coef,
+                       int32_t n_segments, void* stream);
 /* outputs of the last forward on this workspace (logits of 'cls' towers / unit-norm features), for metric tracking
  * (mm.track(loss, outputs, targets), fedavgclient.py:102) */
 int fc_copy_outputs(const fc_model_t* m, void* workspace, size_t workspace_bytes, float* out_img, float* out_txt, void* stream);

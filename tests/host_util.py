@@ -72,7 +72,7 @@ def make_server(rec, device="cpu"):
     return srv
 
 
-def run_aggregation(srv, rec, local_partial=None, owned=None, all_reduce=None):
+def run_aggregation(srv, rec, local_partial=None, owned=None, all_reduce=None, exact=False):
     ids = rec["ids"]
     sizes = {i: srv.clients[i].__len__() for i in ids}
     for i, ds in enumerate(srv.global_models.keys()):
@@ -80,7 +80,7 @@ def run_aggregation(srv, rec, local_partial=None, owned=None, all_reduce=None):
         srv.task, srv.modality = DS[ds]
         srv.dataset = ds
         srv.out_modality_scale = rec["out_modality_scales"][i]
-        srv._aggregate(ids, sizes, local_partial=local_partial, all_reduce=all_reduce)
+        srv._aggregate(ids, sizes, local_partial=local_partial, all_reduce=all_reduce, exact=exact)
 
 
 def check_aggregation(srv, rec, tol=2e-6):
@@ -88,3 +88,28 @@ def check_aggregation(srv, rec, tol=2e-6):
         sd = srv.global_models[ds].state_dict()
         for k, r in exp.items():
             G.compare(sd[k], r, tol, tol, f"agg {rec['shared_param']}/{rec['share_scope']}/comp={rec['compensation']} {ds} {k}")
+
+
+def oracle_sequential_blend(srv, rec):
+    """Expected global models of ``rec`` from the oracle's restatement of the reference loop (fp32 on the CPU), computed from the
+    same starting point as ``srv`` -- call BEFORE running the aggregation.  Returns {dataset: {key: tensor}}."""
+    from oracle import aggregate_oracle as AO
+    ids = rec["ids"]
+    sizes = {i: len(srv.clients[i]) for i in ids}
+    layers = ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
+    uploads = {}
+    for i in ids:
+        c = srv.clients[i]
+        sd = {k: v.detach().cpu().clone() for k, v in c.model.state_dict().items()}
+        uploads[i] = AO.upload_fold(sd, layers) if (rec["with_aux"] and c.modality != "img+txt") else sd
+    infos = {c.id: AO.ClientInfo(c.dataset, c.task, c.modality) for c in srv.clients}
+    out = {}
+    for n, ds in enumerate(srv.global_models.keys()):
+        gm = srv.global_models[ds]
+        g = {k: v.detach().cpu().clone() for k, v in gm.required_params().items()}
+        task, modality = DS[ds]
+        coef = AO.coefficients(list(g.keys()), srv.param_scope, ids, sizes, infos, dataset=ds, task=task, modality=modality,
+                               out_modality_scale=rec["out_modality_scales"][n], compensation=rec["compensation"],
+                               share_scope=rec["share_scope"], arg_modalities=srv.args.modalities)
+        out[ds] = AO.sequential_blend(g, uploads, ids, coef)
+    return out
