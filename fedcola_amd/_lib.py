@@ -88,6 +88,7 @@ SIGNATURES = {
     "fc_copy_outputs": (C.c_int, [_P, _P, _Z, _P, _P, _P]),
     "fc_scale_segments": (C.c_int, [_P, _P, _P, _P, _I, _P]),
     "fc_upload_fold": (C.c_int, [_P, _P, _P, _P]),
+    "fc_workspace_tensor": (C.c_int, [_P, _I, _I, _I, _I, C.c_char_p, C.POINTER(_Z), C.POINTER(_Z)]),
     "fc_k_layernorm_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "fc_k_layernorm_bwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "fc_k_gemm": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P]),

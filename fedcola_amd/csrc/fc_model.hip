@@ -1216,6 +1216,44 @@ extern "C" int fc_scale_segments(float* buf, const int64_t* seg_offset, const in
   return fc_scale_segments_impl(buf, seg_offset, seg_numel, seg_weight, n_segments, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------- workspace inspection (tests: op-by-op parity of the bf16 path)
+extern "C" int fc_workspace_tensor(const fc_model_t* m, int32_t B, int32_t n_txt, int32_t tower, int32_t layer, const char* name, size_t* offset,
+                                   size_t* bytes) {
+  FC_REQUIRE(m && name && offset && bytes, "fc_workspace_tensor: null argument");
+  FC_REQUIRE(tower >= 0 && tower < 2 && m->tw[tower].present, "fc_workspace_tensor: tower %d absent", tower);
+  Ws w;
+  carve(m, B, m->tw[1].present ? n_txt : 0, (void*)256, w);      // any non-null base: offsets are differences
+  char* base = (char*)256;
+  const TowerWs& t = w.t[tower];
+  const fc_model_cfg& c = m->cfg;
+  const size_t es = fc_esize(m->dt), MD = (size_t)t.M * c.dim * es, MH = (size_t)t.M * c.mlp_hidden * es, M4 = sizeof(float) * (size_t)t.M;
+  const void* p = nullptr;
+  size_t n = 0;
+  const std::string k = name;
+  if (k == "x" || k == "gx") {
+    FC_REQUIRE(layer >= 0 && layer <= c.depth, "fc_workspace_tensor: layer %d out of range", layer);
+    p = k == "x" ? t.x[layer] : t.gx[layer]; n = MD;
+  } else if (k == "patches") { p = t.patches; n = (size_t)B * (t.N - 1) * c.in_chans * c.patch * c.patch * es; }
+  else if (k == "dtok") { p = t.dtok; n = (size_t)B * (t.N - 1) * c.dim * es; }
+  else if (k == "out") { p = t.out; n = sizeof(float) * (size_t)B * c.dim; }
+  else if (k == "f") { p = t.f; n = sizeof(float) * (size_t)B * c.dim; }
+  else if (k == "dout") { p = w.dout[tower]; n = sizeof(float) * (size_t)B * c.dim; }
+  else {
+    FC_REQUIRE(layer >= 0 && layer < c.depth, "fc_workspace_tensor: layer %d out of range", layer);
+    const LayerWs& L = t.L[layer];
+    if (k == "h1") { p = L.h1; n = MD; } else if (k == "qkv") { p = L.qkv; n = 3 * MD; } else if (k == "o") { p = L.o; n = MD; }
+    else if (k == "xmid") { p = L.xmid; n = MD; } else if (k == "h2") { p = L.h2; n = MD; } else if (k == "u") { p = L.u; n = MH; }
+    else if (k == "gact") { p = L.gact; n = MH; } else if (k == "gxmid") { p = L.gxmid; n = MD; } else if (k == "gdm") { p = L.gdm; n = MD; }
+    else if (k == "gda") { p = L.gda; n = MD; } else if (k == "gdu") { p = L.gdu; n = MH; } else if (k == "gdqkv") { p = L.gdqkv; n = 3 * MD; }
+    else if (k == "mean1") { p = L.mean1; n = M4; } else if (k == "rstd1") { p = L.rstd1; n = M4; } else if (k == "mean2") { p = L.mean2; n = M4; }
+    else if (k == "rstd2") { p = L.rstd2; n = M4; } else if (k == "lse") { p = L.lse; n = sizeof(float) * (size_t)B * c.heads * t.N; }
+  }
+  FC_REQUIRE(p != nullptr, "fc_workspace_tensor: unknown tensor '%s'", name);
+  *offset = (size_t)((const char*)p - base);
+  *bytes = n;
+  return 0;
+}
+
 // ---------------------------------------------------------------- kernel-level test entry points
 extern "C" int fc_k_layernorm_fwd(int32_t dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int32_t M,
                                   int32_t D, float eps, void* stream) {

@@ -245,7 +245,7 @@ class ModalityAgnosticTransformer(nn.Module):
         new = ModalityAgnosticTransformer.__new__(ModalityAgnosticTransformer)
         nn.Module.__init__(new)
         for k, v in self.__dict__.items():
-            if k in ("_parameters", "_buffers", "_modules", "_wc", "_ws", "_views", "_handle"):
+            if k in ("_parameters", "_buffers", "_modules", "_wc", "_ws", "_views", "_handle", "_dp_keep", "_agg_partial"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._handle = _Handle(self._handle.cfg)
@@ -302,7 +302,10 @@ class ModalityAgnosticTransformer(nn.Module):
         """timm DropPath multipliers [2, depth, 2, B] (0 or 1/keep), drawn on device; None when inactive (eval / rate 0)."""
         if not self.training or self.drop_path_rate <= 0.0:
             return None
-        keep = 1.0 - torch.tensor(self.dpr, dtype=torch.float32, device=self.flat.device).view(1, self.depth, 1, 1)
+        keep = getattr(self, "_dp_keep", None)
+        if keep is None or keep.device != self.flat.device:      # constant table: uploaded once (a per-step H2D copy stalls the launch queue)
+            keep = 1.0 - torch.tensor(self.dpr, dtype=torch.float32).view(1, self.depth, 1, 1).to(self.flat.device)
+            self._dp_keep = keep
         u = torch.rand(2, self.depth, 2, B, device=self.flat.device, generator=generator)
         return ((u < keep).float() / keep).contiguous()
 

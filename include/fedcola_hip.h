@@ -217,6 +217,14 @@ size_t fc_retrieval_scratch_bytes(int32_t nq_batch, int32_t ng);
 int fc_retrieval_best_ranks(const double* q, const double* g, const int64_t* q_labels, const int64_t* g_labels, int32_t nq,
                             int32_t ng, int32_t d, void* scratch, size_t scratch_bytes, int64_t* best_ranks, void* stream);
 
+/* ---- workspace inspection (tests: op-by-op parity of the bf16 path against the oracle on the library's own intermediates).
+ * Byte offset / size of a saved tensor inside the workspace of (B, n_txt): tower 0 = image, 1 = text; names: per tower "x" / "gx"
+ * (layer 0..depth: residual stream and its gradient), "patches", "dtok", "f", "out", "dout"; per layer "h1" "qkv" "o" "xmid" "h2"
+ * "u" (bf16 mode: gelu'(u)) "gact" "gxmid" "gdm" "gda" "gdu" "gdqkv" "mean1" "rstd1" "mean2" "rstd2" "lse".
+ * Activations are in the model's precision, statistics / features in fp32. */
+int fc_workspace_tensor(const fc_model_t* m, int32_t B, int32_t n_txt, int32_t tower, int32_t layer, const char* name, size_t* offset,
+                        size_t* bytes);
+
 /* ---- individual kernels exposed for unit tests / reuse (dt: 0 = f32, 1 = bf16) */
 int fc_k_layernorm_fwd(int32_t dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
                        int32_t M, int32_t D, float eps, void* stream);

@@ -76,6 +76,28 @@ class OracleCfg:
         return ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
 
 
+# --------------------------------------------------------------------------- bf16 emulation of the throughput mode
+# The product's bf16 mode (precision='bf16', the mode bench.py times) keeps activations and compute weights in bf16 and
+# accumulates in fp32.  `with emulate_bf16():` makes this oracle round at exactly the points where the HIP kernels store
+# or pack bf16 (DESIGN.md section 4 lists them), so that the timed path can be held to a tight tolerance instead of the
+# loose "8 mantissa bits, 12 layers deep" bound.  Outside the context R() is the identity and nothing changes.
+_EMULATE = [False]
+
+
+class emulate_bf16:
+    def __enter__(self):
+        self.prev = _EMULATE[0]
+        _EMULATE[0] = True
+
+    def __exit__(self, *a):
+        _EMULATE[0] = self.prev
+
+
+def R(t: Tensor) -> Tensor:
+    """Round to bf16 (nearest even) and back, inside `emulate_bf16()`; identity otherwise."""
+    return t.to(torch.bfloat16).to(t.dtype) if _EMULATE[0] else t
+
+
 LN_EPS_BLOCK = 1e-5   # nn.LayerNorm default, mome.py:199,203,215
 LN_EPS_FINAL = 1e-6   # mome.py:751
 LN_EPS_BERT = 1e-12   # BertConfig.layer_norm_eps default (mome.py:618-626)
@@ -138,33 +160,45 @@ def _lin_weight(p: Dict[str, Tensor], prefix: str):
 
 
 def block_fwd(p, pre: str, x: Tensor, heads: int, dp1: Optional[Tensor], dp2: Optional[Tensor]):
-    """Block.forward mome.py:225-228.  dp1/dp2: per-sample drop-path multipliers [B] (already /keep)."""
+    """Block.forward mome.py:225-228.  dp1/dp2: per-sample drop-path multipliers [B] (already /keep).
+    R(): bf16 storage points of the throughput mode (identity unless emulate_bf16())."""
     B, N, D = x.shape
     d = D // heads
     scale = d ** -0.5
     h1, s1 = ln_fwd(x, p[pre + ".norm1.weight"], p[pre + ".norm1.bias"], LN_EPS_BLOCK)
-    Wqkv = _lin_weight(p, pre + ".attn.qkv")
-    qkv = linear_fwd(h1, Wqkv, p[pre + ".attn.qkv.bias"])
+    h1 = R(h1)
+    Wqkv = R(_lin_weight(p, pre + ".attn.qkv"))
+    qkv = R(linear_fwd(h1, Wqkv, p[pre + ".attn.qkv.bias"]))
     qkv5 = qkv.reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)          # mome.py:153
     q, k, v = qkv5[0] * scale, qkv5[1], qkv5[2]                            # mome.py:156
     S = q @ k.transpose(-2, -1)                                           # mome.py:157 (fp32)
-    P = torch.softmax(S, dim=-1)                                          # mome.py:162
-    O = (P @ v).transpose(1, 2).reshape(B, N, D)                          # mome.py:165
-    Wproj = _lin_weight(p, pre + ".attn.proj")
+    if _EMULATE[0]:   # the kernel packs exp(S - max) to bf16 for the PV product and divides by the fp32 row sum afterwards
+        mx = S.max(-1, keepdim=True).values
+        e = torch.exp(S - mx)
+        l = e.sum(-1, keepdim=True)
+        P = e / l
+        O4 = (R(e) @ v) / l
+    else:
+        P = torch.softmax(S, dim=-1)                                      # mome.py:162
+        O4 = P @ v
+    O = R(O4.transpose(1, 2).reshape(B, N, D))                            # mome.py:165
+    Wproj = R(_lin_weight(p, pre + ".attn.proj"))
     a = linear_fwd(O, Wproj, p[pre + ".attn.proj.bias"])
     if dp1 is not None:
         a = a * dp1.view(B, 1, 1)
-    x1 = x + a
+    x1 = R(x + a)
     h2, s2 = ln_fwd(x1, p[pre + ".norm2.weight"], p[pre + ".norm2.bias"], LN_EPS_BLOCK)
-    W1 = _lin_weight(p, pre + ".mlp.fc1")
+    h2 = R(h2)
+    W1 = R(_lin_weight(p, pre + ".mlp.fc1"))
     u = linear_fwd(h2, W1, p[pre + ".mlp.fc1.bias"])
-    gact = gelu_fwd(u)
-    W2 = _lin_weight(p, pre + ".mlp.fc2")
+    gact = R(gelu_fwd(u))
+    gp = R(gelu_grad(u)) if _EMULATE[0] else None                         # the bf16 mode saves gelu'(u), not u
+    W2 = R(_lin_weight(p, pre + ".mlp.fc2"))
     m = linear_fwd(gact, W2, p[pre + ".mlp.fc2.bias"])
     if dp2 is not None:
         m = m * dp2.view(B, 1, 1)
-    x2 = x1 + m
-    cache = dict(s1=s1, h1=h1, q=q, k=k, v=v, P=P, O=O, s2=s2, h2=h2, u=u, gact=gact,
+    x2 = R(x1 + m)
+    cache = dict(s1=s1, h1=h1, q=q, k=k, v=v, P=P, O=O, s2=s2, h2=h2, u=u, gact=gact, gp=gp,
                  dp1=dp1, dp2=dp2, Wqkv=Wqkv, Wproj=Wproj, W1=W1, W2=W2)
     return x2, cache
 
@@ -190,34 +224,43 @@ def block_bwd(p, pre: str, dx2: Tensor, c, heads: int, grads, aux_trained: bool)
     d = D // heads
     scale = d ** -0.5
     # ---- MLP branch
-    dm = dx2 if c["dp2"] is None else dx2 * c["dp2"].view(B, 1, 1)
+    dm = dx2 if c["dp2"] is None else R(dx2 * c["dp2"].view(B, 1, 1))
     dg, dW2, db2 = linear_bwd(dm, c["gact"], c["W2"])
     _lin_grads(grads, p, pre + ".mlp.fc2", dW2, db2, aux_trained)
-    du = dg * gelu_grad(c["u"])
+    du = R(dg * (c["gp"] if c["gp"] is not None else gelu_grad(c["u"])))
     dh2, dW1, db1 = linear_bwd(du, c["h2"], c["W1"])
+    dh2 = R(dh2)
     _lin_grads(grads, p, pre + ".mlp.fc1", dW1, db1, aux_trained)
     dx1n, dg2, dbb2 = ln_bwd(dh2, p[pre + ".norm2.weight"], c["s2"])
     _acc(grads, pre + ".norm2.weight", dg2)
     _acc(grads, pre + ".norm2.bias", dbb2)
-    dx1 = dx2 + dx1n
+    dx1 = R(dx2 + dx1n)
     # ---- attention branch
-    da = dx1 if c["dp1"] is None else dx1 * c["dp1"].view(B, 1, 1)
+    da = dx1 if c["dp1"] is None else R(dx1 * c["dp1"].view(B, 1, 1))
     dO, dWp, dbp = linear_bwd(da, c["O"], c["Wproj"])
+    dO = R(dO)
     _lin_grads(grads, p, pre + ".attn.proj", dWp, dbp, aux_trained)
     dO4 = dO.reshape(B, N, heads, d).transpose(1, 2)                      # [B,H,N,d]
     P, q, k, v = c["P"], c["q"], c["k"], c["v"]
-    dV = P.transpose(-2, -1) @ dO4
     dP = dO4 @ v.transpose(-2, -1)
-    dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+    if _EMULATE[0]:   # delta from the stored (rounded) output rows; P and dS are packed to bf16 as MFMA operands
+        O4 = c["O"].reshape(B, N, heads, d).transpose(1, 2)
+        delta = (dO4 * O4).sum(-1, keepdim=True)
+        dS = R(P * (dP - delta))
+        dV = R(P).transpose(-2, -1) @ dO4
+    else:
+        dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+        dV = P.transpose(-2, -1) @ dO4
     dq = (dS @ k) * scale                                                 # q was pre-scaled
     dk = dS.transpose(-2, -1) @ q
-    dqkv = torch.stack([dq, dk, dV], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * D)
+    dqkv = R(torch.stack([dq, dk, dV], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * D))
     dh1, dWq, dbq = linear_bwd(dqkv, c["h1"], c["Wqkv"])
+    dh1 = R(dh1)
     _lin_grads(grads, p, pre + ".attn.qkv", dWq, dbq, aux_trained)
     dxn, dg1, dbb1 = ln_bwd(dh1, p[pre + ".norm1.weight"], c["s1"])
     _acc(grads, pre + ".norm1.weight", dg1)
     _acc(grads, pre + ".norm1.bias", dbb1)
-    return dx1 + dxn
+    return R(dx1 + dxn)
 
 
 def forward(p: Dict[str, Tensor], cfg: OracleCfg, x: Sequence[Optional[Tensor]], feat_out: bool = False,
@@ -238,13 +281,14 @@ def forward(p: Dict[str, Tensor], cfg: OracleCfg, x: Sequence[Optional[Tensor]],
             if img.dim() == 4 and img.shape[1] == 1:                      # mome.py:893-894
                 img = img.repeat(1, 3, 1, 1)
             assert img.shape[2] == cfg.img_size and img.shape[3] == cfg.img_size   # mome.py:262
-            pt = patchify(img, cfg.patch)
-            Wp = p[f"embeddings.{i}.embed.proj.weight"].reshape(cfg.D, -1)
+            pt = R(patchify(img, cfg.patch))
+            Wp = R(p[f"embeddings.{i}.embed.proj.weight"].reshape(cfg.D, -1))
             tok = linear_fwd(pt, Wp, p[f"embeddings.{i}.embed.proj.bias"])
             B = tok.shape[0]
             cls = p[f"embeddings.{i}.cls_token"].expand(B, -1, -1)
-            h = torch.cat([cls, tok], 1) + p[f"embeddings.{i}.pos_embed"]
+            h = R(torch.cat([cls, tok], 1) + p[f"embeddings.{i}.pos_embed"])
             tc["patches"] = pt
+            tc["Wp"] = Wp
         else:
             ids = x[i]
             pre = f"embeddings.{i}.text_embeddings"
@@ -252,6 +296,7 @@ def forward(p: Dict[str, Tensor], cfg: OracleCfg, x: Sequence[Optional[Tensor]],
             e = p[pre + ".word_embeddings.weight"][ids] + p[pre + ".token_type_embeddings.weight"][0] \
                 + p[pre + ".position_embeddings.weight"][:Nt]
             h, tc["emb_ln"] = ln_fwd(e, p[pre + ".LayerNorm.weight"], p[pre + ".LayerNorm.bias"], LN_EPS_BERT)
+            h = R(h)
             tc["ids"] = ids
         tc["blocks"] = []
         for l in range(cfg.depth):
@@ -293,6 +338,7 @@ def backward(p: Dict[str, Tensor], cfg: OracleCfg, cache, d_outs: Sequence[Optio
         dfeats = torch.zeros(B, N, D, dtype=dout.dtype)
         dfeats[:, 0] = df
         dh, dgn, dbn = ln_bwd(dfeats, p["norm.weight"], tc["final_ln"])
+        dh = R(dh)
         _acc(grads, "norm.weight", dgn)                                   # shared by both towers
         _acc(grads, "norm.bias", dbn)
         for l in reversed(range(cfg.depth)):
@@ -301,7 +347,7 @@ def backward(p: Dict[str, Tensor], cfg: OracleCfg, cache, d_outs: Sequence[Optio
             _acc(grads, f"embeddings.{i}.pos_embed", dh.sum(0, keepdim=True))
             _acc(grads, f"embeddings.{i}.cls_token", dh[:, 0].sum(0).reshape(1, 1, D))
             dtok = dh[:, 1:]
-            _, dWp, dbp = linear_bwd(dtok, tc["patches"], p[f"embeddings.{i}.embed.proj.weight"].reshape(cfg.D, -1))
+            _, dWp, dbp = linear_bwd(dtok, tc["patches"], tc["Wp"])
             _acc(grads, f"embeddings.{i}.embed.proj.weight", dWp.reshape(p[f"embeddings.{i}.embed.proj.weight"].shape))
             _acc(grads, f"embeddings.{i}.embed.proj.bias", dbp)
         else:

@@ -1,6 +1,7 @@
 """Full-size parity on the GPU: mome_small_patch16 (ViT-S + 12x384 text tower, vocab 7732, 32-token captions), B=64 --
 BASELINE.json's config[1] -- one client step against the oracle on the same synthetic batch.
-fp32 mode: <= 1e-4 relative on features, loss and every gradient tensor; bf16 mode: the stated bf16 tolerance."""
+fp32 mode: <= 1e-4 relative on features, loss and every gradient tensor.  The bf16 (timed) mode is held to the emulating oracle in
+tests/test_gpu_bf16_parity.py (layer-local 1e-2 relative L2 on every tensor, end-to-end statistical bound)."""
 import pytest
 import torch
 
@@ -41,7 +42,7 @@ def oracle_result():
     return sd, img, ids, outs, float(loss), grads
 
 
-@pytest.mark.parametrize("prec,otol,gtol", [("fp32", 1e-4, 1e-4), ("bf16", 3e-2, 8e-2)])
+@pytest.mark.parametrize("prec,otol,gtol", [("fp32", 1e-4, 1e-4)])
 def test_vit_s_b64_step_vs_oracle(oracle_result, prec, otol, gtol):
     sd, img, ids, outs_o, loss_o, grads_o = oracle_result
     model = PU.build_product(MK, prec, sd)
@@ -66,8 +67,7 @@ def test_vit_s_b64_step_vs_oracle(oracle_result, prec, otol, gtol):
 MKB = dict(embed_dim=768, depth=2, num_heads=12, vocab_size=30522, max_text_len=40)
 
 
-@pytest.mark.parametrize("kind,prec,otol,gtol", [("img+txt", "fp32", 1e-4, 1e-4), ("img+txt", "bf16", 3e-2, 0.15), ("img", "fp32", 1e-4, 1e-4),
-                                                 ("img", "bf16", 3e-2, 0.15)])   # bf16: 8-row batches of synthetic weights, see below
+@pytest.mark.parametrize("kind,prec,otol,gtol", [("img+txt", "fp32", 1e-4, 1e-4), ("img", "fp32", 1e-4, 1e-4)])
 def test_vit_b_width_step_vs_oracle(kind, prec, otol, gtol):
     from fedcola_amd.mome import ModalityAgnosticTransformer as M
     from synth import det_state_dict
@@ -103,7 +103,4 @@ def test_vit_b_width_step_vs_oracle(kind, prec, otol, gtol):
         else:
             worst1d = max(worst1d, (k, rel), key=lambda t: t[1])
     assert worst[1] <= gtol, f"worst gradient tensor {worst}"
-    # bf16 only: bias / LayerNorm / embedding gradients are column (or scattered row) sums over B*N rows (320 text rows here) that cancel almost completely (the
-    # key bias exactly); the 2^-9 rounding of each bf16 summand is then comparable to the sum itself.  They are held to 1e-4 in
-    # fp32 mode above and only bounded here.
-    assert worst1d[1] <= 0.6, f"worst 1-D gradient tensor {worst1d}"
+    assert worst1d[1] <= gtol, f"worst 1-D gradient tensor {worst1d}"
