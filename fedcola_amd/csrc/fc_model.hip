@@ -51,6 +51,11 @@ struct fc_model {
   mutable std::vector<char> clip_host;            // ... and for the gradient-clipping chunk table
   mutable const void* clip_dev = nullptr;
   mutable const void* ln_dev = nullptr;
+  // device tables of the grouped launches (weight-gradient problems, LayerNorm reductions): owned by the handle, so that a cached
+  // table can never be overwritten behind the cache's back (a caller-owned workspace can be freed and come back at the same
+  // address with other contents)
+  mutable void* tables_dev = nullptr;
+  mutable size_t tables_bytes = 0;
   // the two towers are independent until the loss: the text tower runs on a side stream, forked/joined with events
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -61,6 +66,7 @@ struct fc_model {
   mutable hipStream_t mbs[3] = {nullptr, nullptr, nullptr};      // micro-batch chains 1..3 (chain 0 runs on the caller's stream)
   mutable hipEvent_t ev_mb_join[3] = {nullptr, nullptr, nullptr};
   ~fc_model() {
+    if (tables_dev) (void)hipFree(tables_dev);
     if (ev_dw_in) (void)hipEventDestroy(ev_dw_in);
     for (int k = 0; k < 3; ++k) {
       if (ev_dw_in2[k]) (void)hipEventDestroy(ev_dw_in2[k]);
@@ -648,9 +654,38 @@ static int check_ws(const fc_model* m, int B, int n_txt, void* workspace, size_t
   return 0;
 }
 
+// the internal streams / events / tables belong to the CURRENT device: it must be the one that holds the caller's buffers
+static int check_device(const void* p, const char* what) {
+  hipPointerAttribute_t at;
+  int cur = -1;
+  if (p && hipPointerGetAttributes(&at, p) == hipSuccess && hipGetDevice(&cur) == hipSuccess)
+    FC_REQUIRE(at.device == cur, "%s: the buffers live on device %d but the current device is %d (hipSetDevice / torch.cuda.device first)", what,
+               at.device, cur);
+  else
+    (void)hipGetLastError();
+  return 0;
+}
+static int ensure_tables(const fc_model* m, const Ws& w, hipStream_t s, FcTnProblem** probs, FcLnReduce** lntab) {
+  const size_t need_p = sizeof(FcTnProblem) * (size_t)w.max_probs, need = need_p + sizeof(FcLnReduce) * (size_t)w.max_ln;
+  if (m->tables_bytes < need) {      // first backward of this handle (or a deeper model than before): one small allocation, kept
+    if (m->tables_dev) {
+      FC_CHECK_HIP(hipDeviceSynchronize());
+      FC_CHECK_HIP(hipFree(m->tables_dev));
+    }
+    FC_CHECK_HIP(hipMalloc(&m->tables_dev, need));
+    m->tables_bytes = need;
+    m->probs_host.clear(); m->probs_dev = nullptr;
+    m->ln_host.clear(); m->ln_dev = nullptr;
+  }
+  *probs = (FcTnProblem*)m->tables_dev;
+  *lntab = (FcLnReduce*)((char*)m->tables_dev + need_p);
+  return 0;
+}
+
 static int forward_impl(const fc_model* m, const float* params, const void* wc, const float* img, const int64_t* ids, int B, int n_txt,
                         int feat_out, const float* droppath, void* workspace, size_t wbytes, float* out_img, float* out_txt, hipStream_t s, Ws& w) {
   FC_REQUIRE(params, "params is null");
+  FC_TRY(check_device(params, "fc_forward"));
   if (m->need_wc) FC_REQUIRE(wc && wc != (const void*)params, "this configuration needs a compute-weight buffer (fc_prepare_weights)");
   // 'None modality should have None input.' (mome.py:890)
   FC_REQUIRE(m->tw[0].present == (img != nullptr), "None modality should have None input. (img)");
@@ -874,10 +909,14 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
   std::vector<FcTnProblem> probs;
   std::vector<FcLnReduce> lnq;
   DwState dwst;
+  FC_TRY(check_device(grads, "fc_backward"));
+  FcTnProblem* probs_dev = nullptr;
+  FcLnReduce* lntab_dev = nullptr;
+  FC_TRY(ensure_tables(m, w, s, &probs_dev, &lntab_dev));
   if (m->dt == FC_BF16) {   // dW / db products are queued and launched in grouped chunks on the dW stream
     FC_TRY(ensure_side(m, s));
     c.defer = &probs;
-    dwst.dev = w.probs;
+    dwst.dev = probs_dev;
     dwst.max_probs = w.max_probs;
     c.dw = &dwst;
   }
@@ -947,15 +986,15 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
   }
   if (!lnq.empty()) {
     FC_REQUIRE((int)lnq.size() <= w.max_ln, "internal: too many queued LayerNorm reductions");
-    bool same = m->ln_dev == w.lntab && m->ln_host.size() == lnq.size() &&
+    bool same = m->ln_dev == lntab_dev && m->ln_host.size() == lnq.size() &&
                 memcmp(m->ln_host.data(), lnq.data(), lnq.size() * sizeof(FcLnReduce)) == 0;
     if (!same) {
       FC_CHECK_HIP(hipStreamSynchronize(s));
       m->ln_host = lnq;
-      m->ln_dev = w.lntab;
-      FC_CHECK_HIP(hipMemcpyAsync(w.lntab, m->ln_host.data(), lnq.size() * sizeof(FcLnReduce), hipMemcpyHostToDevice, s));
+      m->ln_dev = lntab_dev;
+      FC_CHECK_HIP(hipMemcpyAsync(lntab_dev, m->ln_host.data(), lnq.size() * sizeof(FcLnReduce), hipMemcpyHostToDevice, s));
     }
-    FC_TRY(fc_ln_reduce_grouped(w.lntab, (int)lnq.size(), m->cfg.dim, s));
+    FC_TRY(fc_ln_reduce_grouped(lntab_dev, (int)lnq.size(), m->cfg.dim, s));
   }
   if (!probs.empty()) {   // every chunk was launched by flush_dw; the main stream continues after the last one
     FC_CHECK_HIP(hipEventRecord(m->ev_dw_out, m->dws));

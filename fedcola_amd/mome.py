@@ -66,8 +66,9 @@ class _MomeFn(torch.autograd.Function):
         g = [g_img.contiguous().float() if ctx.present[0] else None, g_txt.contiguous().float() if ctx.present[1] else None]
         grads = torch.zeros_like(model.flat)
         L = _lib.lib()
-        check(L.fc_backward(model._handle.h, ptr(model.flat), ptr(model._wc_or_flat()), ptr(g[0]), ptr(g[1]), ptr(grads),
-                            ptr(model._ws), model._ws.numel(), _lib.stream_ptr()))
+        with torch.cuda.device(model.flat.device):
+            check(L.fc_backward(model._handle.h, ptr(model.flat), ptr(model._wc_or_flat()), ptr(g[0]), ptr(g[1]), ptr(grads),
+                                ptr(model._ws), model._ws.numel(), _lib.stream_ptr()))
         return grads, None, None, None, None, None
 
 
@@ -116,6 +117,7 @@ class ModalityAgnosticTransformer(nn.Module):
         self._wc_version = -1
         self._ws = None
         self._views: Optional[Dict[str, nn.Parameter]] = None
+        self._alias: Dict[str, str] = {}
         if init:
             self._reference_init()
 
@@ -170,10 +172,58 @@ class ModalityAgnosticTransformer(nn.Module):
         self._wc_version = -1
 
     def sync_shared_weights(self):
-        """mome.py:818-842.  scope=='all' / colearn_param links alias nn.Modules in the reference; with a flat buffer the
-        only configuration the reference's scripts use (colearn_param='none') is a no-op."""
-        if self.colearn_param != "none":
-            raise NotImplementedError("colearn_param != 'none' (module aliasing) is not part of the hot path")
+        """mome.py:818-842.
+        * scope == 'all': the reference puts the main tower's block list into the slot of every absent modality
+          (``self.blockses[i] = self.blockses[main_idx]``), so ``state_dict()`` gains ``blockses.{i}.*`` keys that alias the main
+          tower's tensors.  Here: alias keys that are views of the same flat segments (``_alias``).
+        * colearn_param == 'blocks': the reference's loop only rebinds its loop variable (``blocks = self.blockses[main_idx]``,
+          :832-835) -- no module changes hands.  Reproduced as the no-op it is.
+        * colearn_param == 'attn': the text tower's attention modules ARE replaced by the image tower's (:836-840): shared qkv / proj
+          parameters with gradients from both towers.  Not implemented (no reference script uses it): raises."""
+        main_idx = next(i for i, m in enumerate(self.modalities) if m is not None)
+        self._alias = {}
+        if self.scope == "all":
+            for i, m in enumerate(self.modalities):
+                if m is None:
+                    self._alias[f"blockses.{i}."] = f"blockses.{main_idx}."
+        if self.colearn_param in ("none", "blocks"):
+            return
+        if self.colearn_param == "attn" and sum(m is not None for m in self.modalities) > 1:
+            raise NotImplementedError("colearn_param='attn' (attention modules shared between the towers, mome.py:836-840) is not implemented")
+
+    def _alias_keys(self):
+        """(alias key, target key) pairs created by sync_shared_weights (scope == 'all'), in the target's order."""
+        out = []
+        for apre, tpre in getattr(self, "_alias", {}).items():
+            for k in self.segments:
+                if k.startswith(tpre):
+                    out.append((apre + k[len(tpre):], k))
+        return out
+
+    def pretrain_vit(self, model_strs, loader=None):
+        """mome.py:788-816: map a timm ViT checkpoint per present modality onto this model's keys ('patch_embed' ->
+        'embeddings.{i}.embed', 'blocks.' -> 'blockses.{i}.', cls_token / pos_embed -> 'embeddings.{i}.*'; for the 'ours' checkpoints
+        'head' -> 'heads.head'), load non-strictly, then sync_shared_weights().  ``loader(model_str) -> state_dict`` stands in for
+        ``timm.create_model(model_str, pretrained=True)`` / ``torch.load('pretrain.pt')``, which need files this build cannot fetch."""
+        for i, model_str in enumerate(model_strs):
+            if model_str is None:
+                continue
+            if loader is None:
+                raise NotImplementedError("pretrained timm checkpoints are not available offline (mome.py:788-816): pass loader=")
+            sd = dict(loader(model_str))
+            if "ours" in model_str:
+                for k, v in list(sd.items()):
+                    if "head" in k:
+                        sd[k.replace("head", "heads.head")] = v
+            for k, v in list(sd.items()):
+                if "patch_embed" in k:
+                    sd[k.replace("patch_embed", f"embeddings.{i}.embed")] = v
+                elif "blocks." in k:
+                    sd[k.replace("blocks", f"blockses.{i}")] = v
+            sd[f"embeddings.{i}.cls_token"] = sd["cls_token"]
+            sd[f"embeddings.{i}.pos_embed"] = sd["pos_embed"]
+            self.load_state_dict(sd, strict=False)
+        self.sync_shared_weights()
 
     # ------------------------------------------------------------------ nn.Module surface
     def named_parameters(self, prefix="", recurse=True, remove_duplicate=True):
@@ -184,9 +234,13 @@ class ModalityAgnosticTransformer(nn.Module):
                 self._views[k] = p
         for k, p in self._views.items():
             g = self.flat.grad
-            if g is not None:
-                s = self.segments[k]
+            s = self.segments[k]
+            # frozen segments keep grad None, like the reference's requires_grad=False parameters: torch optimizers skip only
+            # parameters whose grad is None (a zero gradient would still be weight-decayed)
+            if g is not None and s["trainable"]:
                 p.grad = g[s["offset"]: s["offset"] + s["numel"]].view(s["shape"])
+            elif not s["trainable"]:
+                p.grad = None
             yield (prefix + ("." if prefix else "") + k, p)
 
     def parameters(self, recurse=True):
@@ -197,15 +251,19 @@ class ModalityAgnosticTransformer(nn.Module):
         sd = OrderedDict() if destination is None else destination
         for k in self.segments:
             sd[prefix + k] = self._view(k)
+        for ak, tk in self._alias_keys():                  # scope == 'all': the absent tower's slot aliases the main tower
+            sd[prefix + ak] = self._view(tk)
         return sd
 
     @torch.no_grad()
     def load_state_dict(self, state_dict, strict=True, assign=False):
+        alias = dict(self._alias_keys())
         missing = [k for k in self.segments if k not in state_dict]
-        unexpected = [k for k in state_dict if k not in self.segments and not k.endswith("position_ids")]
+        unexpected = [k for k in state_dict if k not in self.segments and k not in alias and not k.endswith("position_ids")]
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
         for k, v in state_dict.items():
+            k = alias.get(k, k)
             if k in self.segments:
                 self._view(k).copy_(v.reshape(self.segments[k]["shape"]))
         self._bump()
@@ -323,9 +381,10 @@ class ModalityAgnosticTransformer(nn.Module):
                 continue
             width = self.embed_dim if (feat_out or self.tasks[i] == "rtv") else int(self.num_classes[i])
             outs[i] = torch.empty(B, width, dtype=torch.float32, device=dev)
-        check(_lib.lib().fc_forward(self._handle.h, ptr(self.flat), ptr(self._wc_or_flat()), ptr(img), ptr(ids), B, n_txt,
-                                    int(bool(feat_out)), ptr(droppath), ptr(ws), ws.numel(), ptr(outs[0]), ptr(outs[1]),
-                                    _lib.stream_ptr()))
+        with torch.cuda.device(dev):      # the library's internal streams / tables belong to the current device
+            check(_lib.lib().fc_forward(self._handle.h, ptr(self.flat), ptr(self._wc_or_flat()), ptr(img), ptr(ids), B, n_txt,
+                                        int(bool(feat_out)), ptr(droppath), ptr(ws), ws.numel(), ptr(outs[0]), ptr(outs[1]),
+                                        _lib.stream_ptr()))
         return outs
 
     def forward(self, x, feat_out=False, droppath=None):
@@ -368,30 +427,30 @@ def create_model(model_name, pretrained=False, **kwargs):
     return _REGISTRY[model_name](pretrained, **kwargs)
 
 
-def _factory(embed_dim, depth, heads):
+def _factory(embed_dim, depth, heads, timm_name=None):
     def build(pretrained, args, **kwargs):
-        if pretrained:
-            raise NotImplementedError("pretrained timm checkpoints are not available offline (mome.py:788-816)")
         model = ModalityAgnosticTransformer(img_size=224, patch_size=16, embed_dim=embed_dim, depth=depth, num_heads=heads,
                                             vocab_size=args.vocab_size, max_text_len=args.seq_len, drop_path_rate=args.dropout,
                                             shared_param=args.shared_param, share_scope=args.share_scope,
                                             colearn_param=args.colearn_param, precision=getattr(args, "precision", "fp32"),
                                             **kwargs)
         model.sync_shared_weights()
+        if pretrained:     # mome.py:951-952: model.pretrain_vit([timm name, None]); the checkpoint comes from args.pretrain_loader here
+            model.pretrain_vit([timm_name, None], loader=getattr(args, "pretrain_loader", None))
         return model
     return build
 
 
-def _register(name, embed_dim, depth, heads):
-    fn = _factory(embed_dim, depth, heads)
+def _register(name, embed_dim, depth, heads, timm_name=None):
+    fn = _factory(embed_dim, depth, heads, timm_name)
     fn.__name__ = fn.__qualname__ = name
     return register_model(fn)
 
 
-mome_small_patch16 = _register("mome_small_patch16", 384, 12, 6)                       # mome.py:924-953
-mome_tiny_patch16 = _register("mome_tiny_patch16", 192, 12, 3)                         # mome.py:955-974
-mome_small_patch16_224_in21k = _register("mome_small_patch16_224_in21k", 384, 12, 6)   # mome.py:976-995
-mome_toy_patch16_224 = _register("mome_toy_patch16_224", 4, 1, 2)                      # mome.py:1016-1033
+mome_small_patch16 = _register("mome_small_patch16", 384, 12, 6, "vit_small_patch16_224")                              # mome.py:924-953
+mome_tiny_patch16 = _register("mome_tiny_patch16", 192, 12, 3, "vit_tiny_patch16_224")                                 # mome.py:955-974
+mome_small_patch16_224_in21k = _register("mome_small_patch16_224_in21k", 384, 12, 6, "vit_small_patch16_224_in21k")    # mome.py:976-995
+mome_toy_patch16_224 = _register("mome_toy_patch16_224", 4, 1, 2)                                                      # mome.py:1016-1033
 # The reference's only 768-wide factory (mome_base_patch16_224_ours, mome.py:998-1014) is broken (passes share_strategy=,
 # skips sync_shared_weights); this build defines the D=768, H=12 model by analogy.
-mome_base_patch16 = _register("mome_base_patch16", 768, 12, 12)
+mome_base_patch16 = _register("mome_base_patch16", 768, 12, 12, "vit_base_patch16_224")

@@ -152,11 +152,39 @@ class CreamflServer(FedavgServer):
             gm._bump()
             torch.cuda.current_stream().synchronize()
 
+    def _exchange_pub_features(self, selected_ids):
+        """One process per GPU: a uni-modal client's public-set features exist only on the rank that trained it this round, but
+        every rank runs the (replicated) feature aggregation and distillation of creamflserver.py:373-435 and must see the same
+        inputs.  Each owner's [P, D] features are all-gathered in selected-id order; a rank that still holds stale features of a
+        client it owned in an earlier round gets them overwritten.  Single process: nothing to do."""
+        from .fedavgserver import _dist
+        dist, rank, world = _dist()
+        if world == 1:
+            return
+        mine = {}
+        for pos, i in enumerate(selected_ids):
+            c = self.clients[i]
+            if c.modality in ("img", "txt") and self._owner_rank(pos, world) == rank:
+                mine[i] = c.pub_features.detach().float().cpu()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        dev = torch.device(self.device)
+        for pos, i in enumerate(selected_ids):
+            c = self.clients[i]
+            if c.modality not in ("img", "txt"):
+                continue
+            owner = self._owner_rank(pos, world)
+            if i not in gathered[owner]:
+                raise RuntimeError(f"client {i}: rank {owner} trained it but sent no public-set features")
+            if owner != rank:
+                c.pub_features = gathered[owner][i].to(dev)
+
     # ------------------------------------------------------------------ one round (:338-435)
     def update(self):
         self._generate_public_logit()
         selected_ids = self._sample_clients()
         updated_sizes = self._request(selected_ids, eval=False, participated=True, retain_model=True, save_raw=False)
+        self._exchange_pub_features(selected_ids)
         img_vec, txt_vec = [], []
         for i in selected_ids:
             c = self.clients[i]

@@ -4,10 +4,16 @@
  * Python/PyTorch); each entry point below names the reference code it replaces so a maintainer can bind it from
  * src/models/mome.py / src/client/fedavgclient.py / src/server/fedavgserver.py with ctypes.
  *
- * Conventions: plain pointers and sizes only; every data pointer is a DEVICE pointer owned by the caller; all
- * work is enqueued asynchronously on the caller's hipStream_t (passed as void*); no hidden allocation, no host
- * synchronisation; return 0 on success, <0 on error (message: fc_last_error()).  A handle is not thread-safe:
- * use one per device/stream.
+ * Conventions: plain pointers and sizes only; every data pointer is a DEVICE pointer owned by the caller (on the
+ * CURRENT device: the calls check it); all work is enqueued asynchronously on the caller's hipStream_t (passed as
+ * void*); return 0 on success, <0 on error (message: fc_last_error()).  A handle is not thread-safe: use one per
+ * device/stream.
+ * Allocation / synchronisation: the steady state (same handle, same workspace address, same batch shape) allocates nothing
+ * and never blocks the host.  The exceptions, each once: the first forward of a process creates the library's internal HIP
+ * streams for the device and measures which of them run concurrently (~10 ms); the first backward of a handle allocates its
+ * table buffer (< 64 KB, freed by fc_model_destroy); a call whose workspace address or batch shape differs from the previous
+ * one re-sends those tables (one stream synchronisation); fc_prox_term / fc_clip_grad_norm copy a <= 50-KB table from host
+ * memory on every call (their scratch is the caller's and may have been reused in between).
  */
 #ifndef FEDCOLA_HIP_H
 #define FEDCOLA_HIP_H

@@ -62,3 +62,54 @@ def test_two_rank_aggregation_matches_reference(idx):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _cream_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import types
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fedcola_amd.server.creamflserver import CreamflServer
+        srv = object.__new__(CreamflServer)
+        srv.device = "cpu"
+        clients = []
+        for i, mod in enumerate(["img", "txt", "img+txt", "img"]):
+            c = types.SimpleNamespace(id=i, modality=mod, pub_features=None)
+            clients.append(c)
+        srv._clients = clients
+        ids = [0, 1, 2, 3]
+        # each rank computed the features of the clients it owns (positions p % world == rank); a stale copy of another rank's
+        # client must be replaced
+        for pos, i in enumerate(ids):
+            if pos % world == rank and clients[i].modality != "img+txt":
+                clients[i].pub_features = torch.full((5, 3), float(10 * i + 1))
+        if rank == 0:
+            clients[1].pub_features = torch.full((5, 3), -7.0)        # stale: client 1 belongs to rank 1 this round
+        srv._exchange_pub_features(ids)
+        for i in (0, 1, 3):
+            assert torch.equal(clients[i].pub_features, torch.full((5, 3), float(10 * i + 1))), (rank, i, clients[i].pub_features)
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_creamfl_public_features_are_exchanged_between_ranks():
+    """CreamflServer.update read c.pub_features of clients trained on other ranks (creamflserver.py:352-366)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cream_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

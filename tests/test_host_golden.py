@@ -195,3 +195,105 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+# ---------------------------------------------------------------------------------------------- A1: sync_shared_weights / pretrain_vit
+def _toy(modalities, **kw):
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    nc = [5 if modalities[0] == "img" else None, 3 if modalities[1] == "txt" else None] if None in modalities else [None, None]
+    tasks = ["cls" if m is not None and None in modalities else ("rtv" if m is not None else None) for m in modalities]
+    return M(modalities=modalities, num_classes=nc, tasks=tasks, embed_dim=8, depth=2, num_heads=2, vocab_size=30, max_text_len=8, **kw)
+
+
+def test_scope_all_aliases_the_absent_tower_to_the_main_blocks():
+    """mome.py:824-827: with share_scope == 'all' a uni-modal model's empty block slot IS the main tower's block list, so
+    state_dict() lists blockses.{absent}.* keys that share storage with blockses.{main}.*; required_params() drops them again."""
+    m = _toy(["img", None], share_scope="all")
+    m.sync_shared_weights()
+    sd = m.state_dict()
+    alias = [k for k in sd if k.startswith("blockses.1.")]
+    main = [k for k in sd if k.startswith("blockses.0.")]
+    assert len(alias) == len(main) > 0
+    for a, t in zip(alias, main):
+        assert a == t.replace("blockses.0.", "blockses.1.", 1)
+        assert sd[a].data_ptr() == sd[t].data_ptr()
+    # reference order: the aliased slot follows every own key of the ModuleList walk only in position, not in content
+    assert all("blockses.1." not in k for k in m.required_params())
+    # named_parameters() de-duplicates shared tensors like nn.Module does
+    assert all(not k.startswith("blockses.1.") for k, _ in m.named_parameters())
+    # a checkpoint written from such a model loads back (alias keys accepted, same values)
+    ck = {k: v.clone() + 1.0 for k, v in sd.items()}
+    m.load_state_dict(ck, strict=True)
+    assert torch.equal(m.state_dict()["blockses.0.0.attn.qkv.weight"], ck["blockses.1.0.attn.qkv.weight"])
+    # scope != 'all': no alias keys
+    m2 = _toy(["img", None], share_scope="modality")
+    m2.sync_shared_weights()
+    assert all(not k.startswith("blockses.1.") for k in m2.state_dict())
+
+
+def test_colearn_param_blocks_is_the_reference_noop_and_attn_is_loud():
+    """mome.py:832-835 rebinds a loop variable only ('blocks' shares nothing); :836-840 ('attn') really aliases modules."""
+    m = _toy(["img", "txt"], colearn_param="blocks")
+    before = list(m.state_dict().keys())
+    m.sync_shared_weights()
+    assert list(m.state_dict().keys()) == before
+    sd = m.state_dict()
+    assert sd["blockses.0.0.attn.qkv.weight"].data_ptr() != sd["blockses.1.0.attn.qkv.weight"].data_ptr()
+    m = _toy(["img", "txt"], colearn_param="attn")
+    with pytest.raises(NotImplementedError):
+        m.sync_shared_weights()
+
+
+def test_pretrain_vit_key_mapping_on_a_synthetic_timm_state_dict():
+    """mome.py:788-816 on a timm-shaped ViT state_dict (cls_token, pos_embed, patch_embed.proj.*, blocks.N.*, norm.*, head.*)."""
+    m = _toy(["img", None])
+    D, depth = 8, 2
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    timm_sd = {"cls_token": rnd(1, 1, D), "pos_embed": rnd(1, 197, D), "patch_embed.proj.weight": rnd(D, 3, 16, 16), "patch_embed.proj.bias": rnd(D),
+               "norm.weight": rnd(D), "norm.bias": rnd(D), "head.weight": rnd(1000, D), "head.bias": rnd(1000)}
+    for l in range(depth):
+        for nm, shp in (("norm1.weight", (D,)), ("norm1.bias", (D,)), ("attn.qkv.weight", (3 * D, D)), ("attn.qkv.bias", (3 * D,)),
+                        ("attn.proj.weight", (D, D)), ("attn.proj.bias", (D,)), ("norm2.weight", (D,)), ("norm2.bias", (D,)),
+                        ("mlp.fc1.weight", (4 * D, D)), ("mlp.fc1.bias", (4 * D,)), ("mlp.fc2.weight", (D, 4 * D)), ("mlp.fc2.bias", (D,))):
+            timm_sd[f"blocks.{l}.{nm}"] = rnd(*shp)
+    seen = []
+    own_head = m.state_dict()["heads.0.head.weight"].clone()
+    m.pretrain_vit(["vit_small_patch16_224", None], loader=lambda name: (seen.append(name), dict(timm_sd))[1])
+    assert seen == ["vit_small_patch16_224"]
+    sd = m.state_dict()
+    assert torch.equal(sd["embeddings.0.cls_token"], timm_sd["cls_token"]) and torch.equal(sd["embeddings.0.pos_embed"], timm_sd["pos_embed"])
+    assert torch.equal(sd["embeddings.0.embed.proj.weight"], timm_sd["patch_embed.proj.weight"])
+    assert torch.equal(sd["embeddings.0.embed.proj.bias"], timm_sd["patch_embed.proj.bias"])
+    for l in range(depth):
+        for nm in ("norm1.weight", "attn.qkv.weight", "attn.proj.bias", "mlp.fc1.weight", "mlp.fc2.bias", "norm2.bias"):
+            assert torch.equal(sd[f"blockses.0.{l}.{nm}"], timm_sd[f"blocks.{l}.{nm}"]), (l, nm)
+    assert torch.equal(sd["norm.weight"], timm_sd["norm.weight"])
+    assert torch.equal(sd["heads.0.head.weight"], own_head)            # timm's 1000-way 'head.*' is not this model's 'heads.0.head.*'
+    with pytest.raises(NotImplementedError):
+        _toy(["img", None]).pretrain_vit(["vit_small_patch16_224", None])   # no checkpoint source offline: loud
+
+
+def test_algorithm_plugin_fedavg_optimizer_is_fedavg():
+    """src/algorithm/fedavg.py:7-55 (dormant plugin point): one accumulate per client with c = n_i / sum n, then step() = weighted mean."""
+    from fedcola_amd.algorithm.fedavg import FedavgOptimizer
+    from fedcola_amd.algorithm.fedprox import FedproxOptimizer
+    g = torch.Generator().manual_seed(0)
+    server = {"a.weight": torch.randn(4, 3, generator=g), "a.bias": torch.randn(4, generator=g), "bn.num_batches_tracked": torch.tensor(7.0)}
+    clients = [{k: torch.randn(v.shape, generator=g) for k, v in server.items()} for _ in range(3)]
+    sizes = [10, 30, 60]
+    start = {k: v.clone() for k, v in server.items()}
+    for cls in (FedavgOptimizer, FedproxOptimizer):
+        for k in server:
+            server[k].copy_(start[k])
+        opt = cls(params=server, lr=1.0)
+        for c, n in zip(clients, sizes):
+            opt.accumulate({k: n / sum(sizes) for k in ("a.weight", "a.bias")}, iter(c.items()))
+        opt.step()
+        for k in ("a.weight", "a.bias"):
+            exp = sum(c[k] * n for c, n in zip(clients, sizes)) / sum(sizes)
+            assert float((server[k] - exp).abs().max()) < 1e-6
+        assert float(server["bn.num_batches_tracked"]) == 7.0          # skipped by check_if
+        opt.zero_grad()
+        opt.step()                                                      # nothing pending: no change
+        assert float((server["a.bias"] - sum(c["a.bias"] * n for c, n in zip(clients, sizes)) / sum(sizes)).abs().max()) < 1e-6

@@ -55,3 +55,29 @@ def test_adamw_step_matches_torch_optim():
         opt.step()
         O.adamw_step(q, g, m, v, step, 1e-3)
     assert float((q - ref_p.detach()).abs().max()) <= 2.4e-7   # 1 ulp of values ~1.5
+
+
+def test_scope_all_alias_keys_match_the_reference():
+    """mome.py:824-827 on the real model: same state_dict key list (as a set and in the aliasing relation) as the flat-buffer mirror."""
+    ref = refstub.load_reference()
+    from fedcola_amd.mome import ModalityAgnosticTransformer as Mine
+    kw = dict(modalities=["img", None], num_classes=[5, None], tasks=["cls", None], embed_dim=8, depth=2, num_heads=2, vocab_size=30, max_text_len=8)
+    r = ref.mome.ModalityAgnosticTransformer(share_scope="all", **kw)
+    r.sync_shared_weights()
+    m = Mine(share_scope="all", **kw)
+    m.sync_shared_weights()
+    rk = [k for k in r.state_dict().keys() if not k.endswith("position_ids")]
+    mk = list(m.state_dict().keys())
+    assert set(rk) == set(mk), (set(rk) ^ set(mk))
+    rsd, msd = r.state_dict(), m.state_dict()
+    for k in rk:
+        if k.startswith("blockses.1."):
+            t = k.replace("blockses.1.", "blockses.0.", 1)
+            assert rsd[k].data_ptr() == rsd[t].data_ptr() and msd[k].data_ptr() == msd[t].data_ptr()
+    assert set(r.required_params().keys()) == set(m.required_params().keys())
+    # colearn_param == 'blocks' changes nothing in the reference either
+    kw2 = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=8, depth=2, num_heads=2, vocab_size=30, max_text_len=8)
+    r2 = ref.mome.ModalityAgnosticTransformer(colearn_param="blocks", **kw2)
+    r2.sync_shared_weights()
+    sd2 = r2.state_dict()
+    assert sd2["blockses.0.0.attn.qkv.weight"].data_ptr() != sd2["blockses.1.0.attn.qkv.weight"].data_ptr()
