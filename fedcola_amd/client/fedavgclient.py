@@ -49,9 +49,12 @@ class FedavgClient(BaseClient):
     def _create_dataloader(self, dataset, shuffle, test=True):
         if self.args.B == 0:
             self.args.B = len(self.training_set)
-        if getattr(self.args, "fast_loader", False):                 # same sampling, threaded assembly into pinned buffers (loaders/batch.py)
+        # device clients: same sampling as the DataLoader below, threaded assembly into pinned buffers (loaders/batch.py); the
+        # reference's single-process DataLoader (fedavgclient.py:44-53) needs 80-130 ms per B = 64 image batch on the MI355X host
+        # against a 5.4-ms device step.  args.fast_loader = False restores it.
+        if getattr(self.args, "fast_loader", torch.cuda.is_available()):
             from ..loaders.batch import PinnedBatchLoader
-            return PinnedBatchLoader(dataset, self.args.B, shuffle=shuffle, workers=getattr(self.args, "loader_workers", 8))
+            return PinnedBatchLoader(dataset, self.args.B, shuffle=shuffle, workers=getattr(self.args, "loader_workers", 4))
         return torch.utils.data.DataLoader(dataset=dataset, batch_size=self.args.B, shuffle=shuffle)
 
     # ------------------------------------------------------------------ the hot loop (fedavgclient.py:55-116)

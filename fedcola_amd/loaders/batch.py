@@ -3,8 +3,9 @@
 The reference iterates a single-process ``DataLoader(dataset, batch_size, shuffle)`` (src/client/fedavgclient.py:44-53): 64 samples
 are fetched one by one and ``default_collate`` stacks them into a new pageable tensor -- ~100 ms for a B = 64 batch of 224x224
 fp32 images on the GPU box's host, 18x the device step.  ``PinnedBatchLoader`` keeps the reference's sampling exactly (torch's
-``RandomSampler`` / ``SequentialSampler`` + ``BatchSampler``: the same index order under the same RNG state) but has worker
-threads write every sample straight into a pinned batch buffer (tensor copies release the GIL); the buffers come from torch's
+``RandomSampler`` / ``SequentialSampler`` + ``BatchSampler``: the same index order under the same RNG state) but has a few worker
+threads (each limited to ONE intra-op thread) write contiguous chunks of samples straight into a pinned batch buffer (tensor copies
+release the GIL); the buffers come from torch's
 caching pinned allocator, which does not recycle a block while an asynchronous H2D copy from it is in flight, so the batches can
 be handed to ``DevicePrefetcher`` as they are.  A dataset may offer ``get_batch(indices) -> tuple of stacked fields`` (same fields as
 ``__getitem__``); then the per-sample Python overhead (the remaining ~20 ms per batch) disappears as well."""
@@ -18,8 +19,15 @@ import torch
 from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
 
 
+def _worker_init():
+    # A tensor copy inside a pool thread would otherwise fan out over torch's intra-op pool (128 threads on the MI355X host): dozens
+    # of pool threads each forking 128-way for a 600-KB copy is what made threaded assembly slower than a plain loop (measured
+    # 3-32 ms per batch, against 4.8 ms for ONE thread and 1.5 ms for 4 single-threaded workers on contiguous chunks).
+    torch.set_num_threads(1)
+
+
 class PinnedBatchLoader:
-    def __init__(self, dataset, batch_size: int, shuffle: bool = False, drop_last: bool = False, workers: int = 8, pin: bool = True, ahead: int = 2):
+    def __init__(self, dataset, batch_size: int, shuffle: bool = False, drop_last: bool = False, workers: int = 4, pin: bool = True, ahead: int = 2):
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
         self.workers, self.pin, self.ahead = max(1, int(workers)), pin and torch.cuda.is_available(), max(0, int(ahead))
 
@@ -27,10 +35,11 @@ class PinnedBatchLoader:
         n = len(self.dataset)
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
-    def _fill(self, bufs, j, i):
-        item = self.dataset[i]
-        for f, v in enumerate(item):
-            bufs[f][j].copy_(torch.as_tensor(v))
+    def _fill_chunk(self, bufs, j0, idxs):
+        for j, i in enumerate(idxs, j0):
+            item = self.dataset[i]
+            for f, v in enumerate(item):
+                bufs[f][j].copy_(torch.as_tensor(v))
 
     def __iter__(self):
         # DataLoader.__iter__ draws its base seed from the default RNG before the sampler draws the permutation seed: consume the
@@ -38,22 +47,29 @@ class PinnedBatchLoader:
         torch.empty((), dtype=torch.int64).random_()
         sampler = RandomSampler(self.dataset) if self.shuffle else SequentialSampler(self.dataset)
         batches = list(BatchSampler(sampler, self.batch_size, self.drop_last))      # every RNG draw happens here, in the caller's thread
+        W = self.workers
 
         def assemble(pool, idxs):
-            if hasattr(self.dataset, "get_batch"):          # vectorised fetch (in-memory / pre-decoded datasets): one gather per field
-                fields = [torch.as_tensor(v) for v in self.dataset.get_batch(idxs)]
-                bufs = [torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=self.pin) for t in fields]
-                list(pool.map(lambda bt: bt[0].copy_(bt[1]), zip(bufs, fields)))
+            n = len(idxs)
+            k = (n + W - 1) // W
+            chunks = [(c * k, idxs[c * k: (c + 1) * k]) for c in range(W) if c * k < n]
+            if hasattr(self.dataset, "get_batch"):          # vectorised fetch (in-memory / pre-decoded datasets): one gather per field and chunk
+                first = [torch.as_tensor(v) for v in self.dataset.get_batch(idxs[:1])]
+                bufs = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=self.pin) for t in first]
+
+                def job(ch):
+                    j0, ii = ch
+                    for buf, t in zip(bufs, self.dataset.get_batch(ii)):
+                        buf[j0: j0 + len(ii)].copy_(torch.as_tensor(t))
+                list(pool.map(job, chunks))
                 return tuple(bufs)
             first = [torch.as_tensor(v) for v in self.dataset[idxs[0]]]
-            bufs = [torch.empty((len(idxs),) + tuple(t.shape), dtype=t.dtype, pin_memory=self.pin) for t in first]
-            for f, t in enumerate(first):
-                bufs[f][0].copy_(t)
-            list(pool.map(lambda ji: self._fill(bufs, ji[0] + 1, ji[1]), enumerate(idxs[1:])))
+            bufs = [torch.empty((n,) + tuple(t.shape), dtype=t.dtype, pin_memory=self.pin) for t in first]
+            list(pool.map(lambda ch: self._fill_chunk(bufs, ch[0], ch[1]), chunks))
             return tuple(bufs)
 
         if self.ahead == 0:
-            with ThreadPoolExecutor(self.workers) as pool:
+            with ThreadPoolExecutor(W, initializer=_worker_init) as pool:
                 for idxs in batches:
                     yield assemble(pool, idxs)
             return
@@ -63,7 +79,7 @@ class PinnedBatchLoader:
 
         def produce():
             try:
-                with ThreadPoolExecutor(self.workers) as pool:
+                with ThreadPoolExecutor(W, initializer=_worker_init) as pool:
                     for idxs in batches:
                         if stop.is_set():
                             return

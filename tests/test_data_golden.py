@@ -185,3 +185,40 @@ def test_pinned_batch_loader_yields_the_dataloaders_batches():
     for a, b in zip(PinnedBatchLoader(DSB(), 6, shuffle=True, ahead=0), ref):
         for x, y in zip(a, b):
             assert x.dtype == y.dtype and torch.equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------- tokenizer (data.py:182-190)
+def test_bert_vocab_tokenizer_matches_hf_golden_ids():
+    import json
+    from fedcola_amd.loaders.tokenizer import BertVocabTokenizer
+    voc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flickr30k_vocab.txt")
+    tok = BertVocabTokenizer(voc)
+    assert tok.vocab_size == 7732                                   # VOCAB_SIZES['Flickr30k'], fedavgserver.py:89-92
+    assert (tok.pad_token_id, tok.unk_token_id, tok.cls_token_id, tok.sep_token_id) == (0, 100, 101, 102)
+    recs = json.load(open(os.path.join(os.path.dirname(voc), "tokenizer.json")))
+    assert len(recs) >= 200
+    for r in recs:
+        got = tok(r["text"], padding="max_length", truncation=True, max_length=r["max_length"], return_tensors="pt")["input_ids"][0]
+        assert got.dtype == torch.int64 and got.tolist() == r["ids"], r["text"][:60]
+    # the partial(tokenizer, padding='max_length', max_length=seq_len, truncation=True) form of data.py:299-303
+    out = tok("a man in a blue shirt", padding="max_length", max_length=12, truncation=True)
+    assert len(out["input_ids"]) == 12 and out["attention_mask"] == [1] * 8 + [0] * 4      # [CLS] + 6 words + [SEP], then 4 x [PAD]
+    assert out["input_ids"][0] == 101 and out["input_ids"][7] == 102 and out["input_ids"][8:] == [0] * 4
+    with pytest.raises(ValueError):
+        BertVocabTokenizer("/nonexistent/vocab.txt")
+
+
+def test_bert_vocab_tokenizer_against_live_hf_tokenizer():
+    """Where transformers is installed (it is in this image): random sentences beyond the golden set."""
+    transformers = pytest.importorskip("transformers")
+    import random
+    from fedcola_amd.loaders.tokenizer import BertVocabTokenizer
+    voc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flickr30k_vocab.txt")
+    hf, mine = transformers.BertTokenizer(voc), BertVocabTokenizer(voc)
+    words = [l.rstrip("\n") for l in open(voc)]
+    rng = random.Random(123)
+    for _ in range(200):
+        s = " ".join(rng.choice(words) if rng.random() > 0.1 else rng.choice(["Xyzzy", "re-do", "it's", "über", "A.B.C", "12:30pm"]) for _ in range(rng.randint(0, 50)))
+        for L in (32, 40):
+            assert mine(s, padding="max_length", truncation=True, max_length=L, return_tensors="pt")["input_ids"][0].tolist() == \
+                hf(s, padding="max_length", truncation=True, max_length=L, return_tensors="pt")["input_ids"][0].tolist(), s

@@ -30,8 +30,8 @@ ds = DS()
 dsb = DSB()
 out = {}
 for name, mk in (("DataLoader", lambda: torch.utils.data.DataLoader(ds, batch_size=64, shuffle=True)),
-                 ("PinnedBatchLoader", lambda: PinnedBatchLoader(ds, 64, shuffle=True, workers=8)),
-                 ("PinnedBatchLoader+get_batch", lambda: PinnedBatchLoader(dsb, 64, shuffle=True, workers=8))):
+                 ("PinnedBatchLoader", lambda: PinnedBatchLoader(ds, 64, shuffle=True, workers=4)),
+                 ("PinnedBatchLoader+get_batch", lambda: PinnedBatchLoader(dsb, 64, shuffle=True, workers=4))):
     list(zip(range(2), mk()))
     t0 = time.perf_counter()
     nb = sum(1 for _ in mk())
@@ -53,8 +53,8 @@ if torch.cuda.is_available():
     L, P = _lib.lib(), _lib.ptr
     e2e = {}
     for name, mk in (("DataLoader", lambda: torch.utils.data.DataLoader(ds, batch_size=64, shuffle=True, drop_last=True)),
-                     ("PinnedBatchLoader", lambda: PinnedBatchLoader(ds, 64, shuffle=True, drop_last=True, workers=8, ahead=2)),
-                     ("PinnedBatchLoader+get_batch", lambda: PinnedBatchLoader(dsb, 64, shuffle=True, drop_last=True, workers=8, ahead=2))):
+                     ("PinnedBatchLoader", lambda: PinnedBatchLoader(ds, 64, shuffle=True, drop_last=True, workers=4, ahead=2)),
+                     ("PinnedBatchLoader+get_batch", lambda: PinnedBatchLoader(dsb, 64, shuffle=True, drop_last=True, workers=4, ahead=2))):
         k = 0
         t0 = None
         for ep in range(2):
