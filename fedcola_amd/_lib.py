@@ -9,7 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfedcola_hip.so")
-if os.environ.get("FC_PROBES_LIB"):      # tools only: the -DFC_PROBES build with the measurement aids (python -m fedcola_amd.build --probes)
+if os.environ.get("FC_LIB_PATH"):         # tools only: A/B runs of two builds on one GPU box (tools/ab_bench.sh)
+    LIB_PATH = os.environ["FC_LIB_PATH"]
+elif os.environ.get("FC_PROBES_LIB"):      # tools only: the -DFC_PROBES build with the measurement aids (python -m fedcola_amd.build --probes)
     LIB_PATH = os.path.join(_HERE, "libfedcola_hip_probes.so")
 
 FC_PREC_FP32, FC_PREC_BF16 = 0, 1
@@ -91,6 +93,8 @@ SIGNATURES = {
     "fc_workspace_tensor": (C.c_int, [_P, _I, _I, _I, _I, C.c_char_p, C.POINTER(_Z), C.POINTER(_Z)]),
     "fc_k_layernorm_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "fc_k_layernorm_bwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fc_k_layernorm_partial_floats": (_Z, [_I, _I]),
+    "fc_k_layernorm_bwd_partial": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "fc_k_gemm": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "fc_k_attention_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fc_k_attention_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
@@ -112,6 +116,8 @@ def lib():
                 "fedcola_amd has no CPU fallback.")
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("FC_LIB_PATH") and not hasattr(l, name):
+                continue                      # an older build in an A/B run
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args

@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(const bf16_t* __restrict_
 }
 
 // ======================================================================== backward
-// Two kernels, each with two tiles (56 KB for N = 197) in LDS so that two workgroups share a CU, each (batch, head) split
-// over two workgroups, inner loops fully unrolled so that independent MFMA chains overlap:
+// Two bodies, each with two tiles (56 KB for N = 197) in LDS so that two workgroups share a CU, one workgroup per (batch, head)
+// and body:
 //   k_attn_bwd_dq : K, V tiles in LDS; Q / dO / O fragments straight from global; waves split the query blocks
 //   k_attn_bwd_dkv: Q, dO tiles in LDS; K / V fragments straight from global; waves split the key blocks (no atomics)
 // delta = rowsum(dO * O) is recomputed inside both kernels (no separate pass, no delta round trip through HBM).
@@ -156,15 +156,17 @@ __device__ __forceinline__ float dot8(const bf16x8& a, const bf16x8& b) {
   return s;
 }
 
+// Register blocking: a wave works on a PAIR of 16-row blocks (32 queries in the dQ body, 32 keys in the dK/dV body) at a time, so
+// every K / V (Q / dO) fragment read from LDS feeds two MFMAs instead of one: half the LDS reads per MFMA of the one-block form
+// (the LDS port, not the matrix pipe, bounded that form), and twice the independent MFMA chains per step to cover their latency.
 template <int NF>
-__device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bid, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N,
                                                  int H, float scale) {
   constexpr int NP = 16 * NF;
   char* Ks = smem;
   char* Vs = smem + NP * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
-  const int bh = bid >> 1, part = bid & 1;
   const int b = bh / H, h = bh % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
@@ -174,56 +176,75 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bid, const bf16
   stage_tile<NP>(Vs, base + 2 * Dm, D3, N, tid);
   __syncthreads();
   bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
-  const int nqb = (N + 15) >> 4;
-  for (int qb = part + 2 * wave; qb < nqb; qb += 8) {
-    const int qrow = qb * 16 + cl;
-    bf16x8 qf[2], dof[2];
-    float dl = 0.f;
+  for (int qp = wave; qp < NF / 2; qp += 4) {             // query pair: rows 32 qp .. 32 qp + 31
+    if (qp * 32 >= N) break;
+    bf16x8 qf[2][2], dof[2][2];
+    float dl[2], lq[2];
+    int qrow[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      qf[ks] = gfrag(base, D3, qrow, N, ks, g);
-      dof[ks] = gfrag(dobase, Dm, qrow, N, ks, g);
-      dl += dot8(dof[ks], gfrag(obase, Dm, qrow, N, ks, g));
-    }
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);                                      // delta[q = cl]
-    const float lq = qrow < N ? lse[((size_t)b * H + h) * N + qrow] : 1e30f;
-    f32x4 dq[4];
+    for (int u = 0; u < 2; ++u) {
+      qrow[u] = (2 * qp + u) * 16 + cl;
+      float acc = 0.f;
 #pragma unroll
-    for (int db = 0; db < 4; ++db) dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int sp = 0; sp < (NF / 2 + 1) / 2; ++sp)
-#pragma unroll
-    for (int ss = 2 * sp; ss < 2 * sp + 2; ++ss) {
-      if (ss >= NF / 2) break;
-      f32x4 ds[2];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int f = 2 * ss + hh;
-        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          st = MFMA(row_frag(Ks, f * 16, ks, lane), qf[ks], st);        // S^T[key][q]
-          dpt = MFMA(row_frag(Vs, f * 16, ks, lane), dof[ks], dpt);     // dP^T[key][q]
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) ds[hh][x] = __expf(st[x] * scale - lq) * (dpt[x] - dl);
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[u][ks] = gfrag(base, D3, qrow[u], N, ks, g);
+        dof[u][ks] = gfrag(dobase, Dm, qrow[u], N, ks, g);
+        acc += dot8(dof[u][ks], gfrag(obase, Dm, qrow[u], N, ks, g));
       }
-      bf16x8 bfg = pack8(ds[0], ds[1]);                                 // B[k = key(8g+j)][col = q = cl]
-#pragma unroll
-      for (int db = 0; db < 4; ++db) dq[db] = MFMA(tr_frag(Ks, 32 * ss, db * 16, lane), bfg, dq[db]);   // dQ^T[d = 16db+4g+x][q = cl]
+      acc += __shfl_xor(acc, 16, 64);
+      acc += __shfl_xor(acc, 32, 64);                                    // delta[q = cl]
+      dl[u] = acc;
+      lq[u] = qrow[u] < N ? lse[((size_t)b * H + h) * N + qrow[u]] : 1e30f;
     }
-    if (qrow < N) {   // a lane owns 4 consecutive head dims of its query row: 8-byte stores
-      bf16_t* p = dbase + (size_t)qrow * D3 + 4 * g;
+    f32x4 dq[2][4];
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
-        *(uint2*)(p + db * 16) = make_uint2(f2bf2(dq[db][0] * scale, dq[db][1] * scale), f2bf2(dq[db][2] * scale, dq[db][3] * scale));
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dq[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ss = 0; ss < NF / 2; ++ss) {                  // key pair: keys 32 ss .. 32 ss + 31
+      bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { kf[hh][ks] = row_frag(Ks, (2 * ss + hh) * 16, ks, lane); vf[hh][ks] = row_frag(Vs, (2 * ss + hh) * 16, ks, lane); }
+      bf16x8 bfg[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            st = MFMA(kf[hh][ks], qf[u][ks], st);          // S^T[key][q]
+            dpt = MFMA(vf[hh][ks], dof[u][ks], dpt);       // dP^T[key][q]
+          }
+#pragma unroll
+          for (int x = 0; x < 4; ++x) ds[hh][x] = __expf(st[x] * scale - lq[u]) * (dpt[x] - dl[u]);
+        }
+        bfg[u] = pack8(ds[0], ds[1]);                      // B[k = key(8g+j)][col = q = cl]
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 kt = tr_frag(Ks, 32 * ss, db * 16, lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) dq[u][db] = MFMA(kt, bfg[u], dq[u][db]);   // dQ^T[d = 16db+4g+x][q = cl]
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (qrow[u] < N) {   // a lane owns 4 consecutive head dims of its query row: 8-byte stores
+        bf16_t* p = dbase + (size_t)qrow[u] * D3 + 4 * g;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+          *(uint2*)(p + db * 16) = make_uint2(f2bf2(dq[u][db][0] * scale, dq[u][db][1] * scale), f2bf2(dq[u][db][2] * scale, dq[u][db][3] * scale));
+      }
   }
 }
 
 template <int NF>
-__device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bid, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                   const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N,
                                                   int H, float scale) {
   constexpr int NP = 16 * NF;
@@ -232,7 +253,6 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bid, const bf1
   float* lse_s = (float*)(Ds + NP * 128);
   float* del_s = lse_s + NP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
-  const int bh = bid >> 1, part = bid & 1;
   const int b = bh / H, h = bh % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
@@ -269,55 +289,78 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bid, const bf1
   }
   __syncthreads();
   bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
-  for (int f = part + 2 * wave; f < NF; f += 8) {
-    if (f * 16 >= N) break;
-    const int krow = f * 16 + cl;
-    bf16x8 kfb[2], vfb[2];
+  for (int kp = wave; kp < NF / 2; kp += 4) {             // key pair: keys 32 kp .. 32 kp + 31
+    if (kp * 32 >= N) break;
+    bf16x8 kfb[2][2], vfb[2][2];
+    int krow[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { kfb[ks] = gfrag(base + Dm, D3, krow, N, ks, g); vfb[ks] = gfrag(base + 2 * Dm, D3, krow, N, ks, g); }
-    f32x4 dv[4], dk[4];
+    for (int u = 0; u < 2; ++u) {
+      krow[u] = (2 * kp + u) * 16 + cl;
 #pragma unroll
-    for (int db = 0; db < 4; ++db) { dv[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      for (int ks = 0; ks < 2; ++ks) { kfb[u][ks] = gfrag(base + Dm, D3, krow[u], N, ks, g); vfb[u][ks] = gfrag(base + 2 * Dm, D3, krow[u], N, ks, g); }
+    }
+    f32x4 dv[2][4], dk[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) { dv[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
-    for (int qq = 0; qq < (NF / 2 + 1) / 2; ++qq)
+    for (int qp = 0; qp < NF / 2; ++qp) {                  // query pair: rows 32 qp .. 32 qp + 31
+      bf16x8 qf[2][2], df[2][2];
 #pragma unroll
-    for (int qp = 2 * qq; qp < 2 * qq + 2; ++qp) {
-      if (qp >= NF / 2) break;
-      f32x4 P[2], dS[2];
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { qf[hh][ks] = row_frag(Qs, (2 * qp + hh) * 16, ks, lane); df[hh][ks] = row_frag(Ds, (2 * qp + hh) * 16, ks, lane); }
+      float lv[2][4], dl[2][4];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const int qb = 2 * qp + hh;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          sa = MFMA(row_frag(Qs, qb * 16, ks, lane), kfb[ks], sa);      // S[q = 4g+x][key = cl]
-          dpa = MFMA(row_frag(Ds, qb * 16, ks, lane), vfb[ks], dpa);    // dP[q][key]
-        }
-        const float4 l4 = *(const float4*)(lse_s + qb * 16 + 4 * g), d4 = *(const float4*)(del_s + qb * 16 + 4 * g);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          float p = __expf(sa[x] * scale - lv[x]);
-          P[hh][x] = p;
-          dS[hh][x] = p * (dpa[x] - dl[x]);
-        }
+        const float4 l4 = *(const float4*)(lse_s + (2 * qp + hh) * 16 + 4 * g), d4 = *(const float4*)(del_s + (2 * qp + hh) * 16 + 4 * g);
+        lv[hh][0] = l4.x; lv[hh][1] = l4.y; lv[hh][2] = l4.z; lv[hh][3] = l4.w;
+        dl[hh][0] = d4.x; dl[hh][1] = d4.y; dl[hh][2] = d4.z; dl[hh][3] = d4.w;
       }
-      bf16x8 pa = pack8(P[0], P[1]), dsa = pack8(dS[0], dS[1]);          // B[k = q(8g+j)][col = key = cl]
+      bf16x8 pa[2], dsa[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x4 P[2], dS[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            sa = MFMA(qf[hh][ks], kfb[u][ks], sa);         // S[q = 4g+x][key = cl]
+            dpa = MFMA(df[hh][ks], vfb[u][ks], dpa);       // dP[q][key]
+          }
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float p = __expf(sa[x] * scale - lv[hh][x]);
+            P[hh][x] = p;
+            dS[hh][x] = p * (dpa[x] - dl[hh][x]);
+          }
+        }
+        pa[u] = pack8(P[0], P[1]);                         // B[k = q(8g+j)][col = key = cl]
+        dsa[u] = pack8(dS[0], dS[1]);
+      }
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        dv[db] = MFMA(tr_frag(Ds, 32 * qp, db * 16, lane), pa, dv[db]);  // dV^T[d = 16db+4g+x][key = cl]
-        dk[db] = MFMA(tr_frag(Qs, 32 * qp, db * 16, lane), dsa, dk[db]); // dK^T[d][key]
-      }
-    }
-    if (krow < N) {   // a lane owns 4 consecutive head dims of its key row: 8-byte stores
-      bf16_t* pk = dbase + (size_t)krow * D3 + Dm + 4 * g;
-      bf16_t* pv = dbase + (size_t)krow * D3 + 2 * Dm + 4 * g;
+        const bf16x8 dt = tr_frag(Ds, 32 * qp, db * 16, lane), qt = tr_frag(Qs, 32 * qp, db * 16, lane);
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        *(uint2*)(pk + db * 16) = make_uint2(f2bf2(dk[db][0] * scale, dk[db][1] * scale), f2bf2(dk[db][2] * scale, dk[db][3] * scale));
-        *(uint2*)(pv + db * 16) = make_uint2(f2bf2(dv[db][0], dv[db][1]), f2bf2(dv[db][2], dv[db][3]));
+        for (int u = 0; u < 2; ++u) {
+          dv[u][db] = MFMA(dt, pa[u], dv[u][db]);          // dV^T[d = 16db+4g+x][key = cl]
+          dk[u][db] = MFMA(qt, dsa[u], dk[u][db]);         // dK^T[d][key]
+        }
       }
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (krow[u] < N) {   // a lane owns 4 consecutive head dims of its key row: 8-byte stores
+        bf16_t* pk = dbase + (size_t)krow[u] * D3 + Dm + 4 * g;
+        bf16_t* pv = dbase + (size_t)krow[u] * D3 + 2 * Dm + 4 * g;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          *(uint2*)(pk + db * 16) = make_uint2(f2bf2(dk[u][db][0] * scale, dk[u][db][1] * scale), f2bf2(dk[u][db][2] * scale, dk[u][db][3] * scale));
+          *(uint2*)(pv + db * 16) = make_uint2(f2bf2(dv[u][db][0], dv[u][db][1]), f2bf2(dv[u][db][2], dv[u][db][3]));
+        }
+      }
   }
 }
 
@@ -334,13 +377,13 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, in
   FC_LAUNCH_CHECK();
   return 0;
 }
-// dQ and dK/dV of one attention backward in ONE launch: blocks [0, 2BH) run the dQ half-tiles, blocks [2BH, 4BH) the dK/dV ones.
+// dQ and dK/dV of one attention backward in ONE launch: blocks [0, BH) run the dQ bodies, blocks [BH, 2BH) the dK/dV ones.
 // The two are independent; as separate launches on one stream the second waited for the first to drain.
 template <int NF>
 __global__ void __launch_bounds__(256, 2) k_attn_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                      const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int half = 2 * B * H;
+  const int half = B * H;
   if ((int)blockIdx.x < half) attn_bwd_dq_body<NF>(smem, blockIdx.x, qkv, o, dout, lse, dqkv, B, N, H, scale);
   else attn_bwd_dkv_body<NF>(smem, blockIdx.x - half, qkv, o, dout, lse, dqkv, B, N, H, scale);
 }
@@ -355,7 +398,7 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, co
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
   }
-  hipLaunchKernelGGL(kb, dim3(B * H * 4), dim3(256), lds, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  hipLaunchKernelGGL(kb, dim3(B * H * 2), dim3(256), lds, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
   FC_LAUNCH_CHECK();
   return 0;
 }

@@ -94,66 +94,88 @@ __global__ void __launch_bounds__(256) k_ln_fwd_v(const T* __restrict__ x, const
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-template <typename T>
+// Backward: a block = 16 rows, a wave owns 4 CONSECUTIVE rows and handles them together: the 12 row loads (dy, x, res of four
+// rows) are in flight at once and the eight wave reductions are interleaved, so a wave pays one memory round trip instead of four
+// dependent ones (measured at M = 12 608, D = 384: 27 us -> see profiles/r02).  dgamma / dbeta: per-lane column sums over the
+// wave's rows, combined across the 4 waves in LDS, one partial row per block (or atomics without `partial`).
+#define LNB_R 4
+template <typename T, int CH>      // CH: 8-column chunks per lane (1: D <= 512)
 __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ g, const T* res, T* dx,
                                                   float* __restrict__ dg, float* __restrict__ db, int M, int D, int rows_per_block,
                                                   float* __restrict__ partial) {
   extern __shared__ float red_dyn[];   // [2][4][D]: sized by the launch, so that narrow models keep many blocks per CU
-  float (*red)[4][1] = nullptr; (void)red;
 #define RED(a, w, i) red_dyn[((a) * 4 + (w)) * D + (i)]
-  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nc = D >> 3;
-  float ag[LNV_MAXC][8], ab[LNV_MAXC][8], gg[LNV_MAXC][8];
+  float ag[CH][8], ab[CH][8], gg[CH][8];
 #pragma unroll
-  for (int t = 0; t < LNV_MAXC; ++t) {
+  for (int t = 0; t < CH; ++t) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { ag[t][i] = 0.f; ab[t][i] = 0.f; gg[t][i] = 0.f; }
     if (lane + 64 * t < nc) V8<float>::ld(g + (lane + 64 * t) * 8, gg[t]);
   }
-  int row0 = blockIdx.x * rows_per_block;
-  for (int r = wave; r < rows_per_block; r += 4) {
-    int row = row0 + r;
-    if (row >= M) break;
-    float mu = mean[row], rs = rstd[row];
-    float d[LNV_MAXC][8], xh[LNV_MAXC][8];
-    float s1 = 0.f, s2 = 0.f;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int per_wave = rows_per_block / 4;                  // consecutive rows of this wave
+  for (int rb = 0; rb < per_wave; rb += LNB_R) {
+    float d[LNB_R][CH][8], xh[LNB_R][CH][8], rr[LNB_R][CH][8];
+    float mu[LNB_R], rs[LNB_R], s1[LNB_R], s2[LNB_R];
+    int row[LNB_R];
 #pragma unroll
-    for (int t = 0; t < LNV_MAXC; ++t) {
-      int c = lane + 64 * t;
-      if (c < nc) {
-        V8<T>::ld(dy + (size_t)row * D + c * 8, d[t]);
-        V8<T>::ld(x + (size_t)row * D + c * 8, xh[t]);
+    for (int q = 0; q < LNB_R; ++q) {                       // every load of the four rows first
+      row[q] = row0 + wave * per_wave + rb + q;
+      const int rc = row[q] < M ? row[q] : M - 1;
+      mu[q] = mean[rc]; rs[q] = rstd[rc];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          xh[t][i] = (xh[t][i] - mu) * rs;
-          float dxh = d[t][i] * gg[t][i];
-          s1 += dxh; s2 += dxh * xh[t][i];
-          ag[t][i] += d[t][i] * xh[t][i]; ab[t][i] += d[t][i];
+      for (int t = 0; t < CH; ++t) {
+        const int c = lane + 64 * t;
+        if (c < nc) {
+          V8<T>::ld(dy + (size_t)rc * D + c * 8, d[q][t]);
+          V8<T>::ld(x + (size_t)rc * D + c * 8, xh[q][t]);
+          if (res) V8<T>::ld(res + (size_t)rc * D + c * 8, rr[q][t]);
         }
       }
     }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int t = 0; t < LNV_MAXC; ++t) {
-      int c = lane + 64 * t;
-      if (c < nc) {
-        float o[8];
+    for (int q = 0; q < LNB_R; ++q) {
+      s1[q] = 0.f; s2[q] = 0.f;
+      const bool live = row[q] < M;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = rs * (d[t][i] * gg[t][i] - s1 - xh[t][i] * s2);
-        if (res) {
-          float rr[8];
-          V8<T>::ld(res + (size_t)row * D + c * 8, rr);
+      for (int t = 0; t < CH; ++t) {
+        if (lane + 64 * t < nc) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] += rr[i];
+          for (int i = 0; i < 8; ++i) {
+            xh[q][t][i] = (xh[q][t][i] - mu[q]) * rs[q];
+            const float dxh = d[q][t][i] * gg[t][i];
+            s1[q] += dxh; s2[q] += dxh * xh[q][t][i];
+            if (live) { ag[t][i] += d[q][t][i] * xh[q][t][i]; ab[t][i] += d[q][t][i]; }
+          }
         }
-        V8<T>::st(dx + (size_t)row * D + c * 8, o);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {                      // the eight reductions side by side
+#pragma unroll
+      for (int q = 0; q < LNB_R; ++q) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
+    }
+#pragma unroll
+    for (int q = 0; q < LNB_R; ++q) {
+      if (row[q] >= M) continue;
+      const float m1 = s1[q] / (float)D, m2 = s2[q] / (float)D;
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        const int c = lane + 64 * t;
+        if (c < nc) {
+          float o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = rs[q] * (d[q][t][i] * gg[t][i] - m1 - xh[q][t][i] * m2) + (res ? rr[q][t][i] : 0.f);
+          V8<T>::st(dx + (size_t)row[q] * D + c * 8, o);
+        }
       }
     }
   }
 #pragma unroll
-  for (int t = 0; t < LNV_MAXC; ++t) {
+  for (int t = 0; t < CH; ++t) {
     int c = lane + 64 * t;
     if (c < nc) {
 #pragma unroll
@@ -285,8 +307,13 @@ int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, c
   if (M <= 0) return 0;
   if (ln_vec_ok(dy, x, dx, res, D) && !((uintptr_t)g & 15)) {
     const int rpb = 16;
-    DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd_v<T>, dim3(fc_cdiv(M, rpb)), dim3(256), sizeof(float) * 8 * D, s, (const T*)dy, (const T*)x, mean, rstd, g,
-                                       (const T*)res, (T*)dx, dg, db, M, D, rpb, partial));
+    if (D <= 512) {
+      DISPATCH_DT(dt, hipLaunchKernelGGL((k_ln_bwd_v<T, 1>), dim3(fc_cdiv(M, rpb)), dim3(256), sizeof(float) * 8 * D, s, (const T*)dy, (const T*)x, mean,
+                                         rstd, g, (const T*)res, (T*)dx, dg, db, M, D, rpb, partial));
+    } else {
+      DISPATCH_DT(dt, hipLaunchKernelGGL((k_ln_bwd_v<T, LNV_MAXC>), dim3(fc_cdiv(M, rpb)), dim3(256), sizeof(float) * 8 * D, s, (const T*)dy, (const T*)x,
+                                         mean, rstd, g, (const T*)res, (T*)dx, dg, db, M, D, rpb, partial));
+    }
     FC_LAUNCH_CHECK();
     return partial ? 1 : 0;   // 1: dg/db are pending in `partial` (caller queues the grouped reduction)
   }

@@ -1160,6 +1160,10 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
                             const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr, float beta1,
                             float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
                             void* stream, const float* global_params, float mu, void* prox_scratch, size_t prox_scratch_bytes);
+#ifdef FC_PROBES
+static hipEvent_t g_phase_ev[64 * 5];
+static bool g_phase_on = false;
+#endif
 extern "C" int fc_client_step(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
                               const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
@@ -1181,6 +1185,14 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
                             float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
                             void* stream, const float* global_params, float mu, void* prox_scratch, size_t prox_scratch_bytes) {
   hipStream_t s = (hipStream_t)stream;
+#ifdef FC_PROBES
+#define FC_PHASE(i) do { if (g_phase_on) (void)hipEventRecord(g_phase_ev[(step & 63) * 5 + (i)], s); } while (0)
+  static const bool g_phase_env = getenv("FC_STEP_PHASES") != nullptr;
+  if (g_phase_env && !g_phase_on) { for (int i = 0; i < 64 * 5; ++i) (void)hipEventCreate(&g_phase_ev[i]); g_phase_on = true; }
+#else
+#define FC_PHASE(i) do {} while (0)
+#endif
+  FC_PHASE(0);
   FC_REQUIRE(grads && exp_avg && exp_avg_sq && lossbuf, "fc_client_step: null buffer");
   FC_REQUIRE(step >= 1, "fc_client_step: step is 1-based");
   bool both = m->tw[0].present && m->tw[1].present;
@@ -1190,6 +1202,7 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
   FC_CHECK_HIP(hipMemsetAsync(lossbuf + 1, 0, sizeof(float), s));
   FC_TRY(forward_impl(m, params, wc, img, ids, B, n_txt, both ? 1 : 0, droppath, workspace, workspace_bytes, nullptr, nullptr, s, w));
   m->last = LastFwd{workspace, B, w.n_txt, both ? 1 : 0, droppath, ids};
+  FC_PHASE(1);
   const float *d0 = nullptr, *d1 = nullptr;
   if (both) {  // fedavgclient.py:91-95
     FC_TRY(fc_contrastive_fwd_bwd(w.t[0].out, w.t[1].out, B, m->cfg.dim, contrastive_tau(), w.loss_scratch, lossbuf, w.dout[0], w.dout[1], s));
@@ -1205,7 +1218,9 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
     if (strstr(sg.name, "aux_weight")) aux_any = true;
   static const bool late_opt = !(getenv("FC_LATE_OPT") && atoi(getenv("FC_LATE_OPT")) == 0);
   LateDw late;
+  FC_PHASE(2);
   FC_TRY(backward_impl(m, params, wc, d0, d1, grads, w, s, (late_opt && !aux_any && !global_params) ? &late : nullptr));
+  FC_PHASE(3);
   if (global_params)   // FedproxClient.update: loss += mu * 0.5 * sum ||p - p_global||, before the optimizer step (fedproxclient.py:64-72)
     FC_TRY(fc_prox_term(m, params, global_params, mu, B, grads, lossbuf, prox_scratch, prox_scratch_bytes, stream));
   // compute weights for the next step: without re-param linears and with every segment trainable the bf16 shadow is written
@@ -1226,8 +1241,22 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
     FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s, fuse_shadow ? (bf16_t*)wc : nullptr));
   }
   if (m->need_wc && !fuse_shadow) FC_TRY(fc_prepare_weights(m, params, wc, stream));
+  FC_PHASE(4);
   return 0;
 }
+#ifdef FC_PROBES
+// tools build only (FC_STEP_PHASES=1): GPU time of the last step's phases on the caller's stream: forward, loss, backward (up to the
+// late weight-gradient chunk), optimizer tail
+extern "C" int fc_dbg_step_phases(int step, float* ms5) {     // [0..3] phases of `step`, [4] gap from the previous step's end to this step's start
+  if (!g_phase_on) return -1;
+  hipEvent_t* e = g_phase_ev + (step & 63) * 5;
+  (void)hipEventSynchronize(e[4]);
+  for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(ms5 + i, e[i], e[i + 1]);
+  ms5[4] = 0.f;
+  if (step > 1) (void)hipEventElapsedTime(ms5 + 4, g_phase_ev[((step - 1) & 63) * 5 + 4], e[0]);
+  return 0;
+}
+#endif
 
 // ---------------------------------------------------------------- aggregation
 extern "C" int fc_aggregate_blend(float* out, const float* global, const float* const* client_bases, int32_t n_clients,
@@ -1301,6 +1330,21 @@ extern "C" int fc_k_layernorm_fwd(int32_t dt, const void* x, const float* g, con
 extern "C" int fc_k_layernorm_bwd(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res,
                                   void* dx, float* dg, float* db, int32_t M, int32_t D, void* stream) {
   return fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, (hipStream_t)stream);
+}
+// the in-model form of the LayerNorm backward: per-block dgamma / dbeta partial rows (room for fc_k_layernorm_partial_floats(M, D)
+// floats) + the grouped reduction, instead of atomics
+extern "C" size_t fc_k_layernorm_partial_floats(int32_t M, int32_t D) { return (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D + 64; }
+extern "C" int fc_k_layernorm_bwd_partial(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
+                                          const void* res, void* dx, float* dg, float* db, int32_t M, int32_t D, float* partial, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, partial);
+  if (r != 1) return r;
+  // one-entry reduction table at the tail of `partial` (the grouped reduction adds into dg / db)
+  FcLnReduce e{partial, dg, db, fc_layernorm_bwd_partial_blocks(M), D};
+  FcLnReduce* tab = (FcLnReduce*)(partial + (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D);
+  FC_CHECK_HIP(hipMemcpyAsync(tab, &e, sizeof(e), hipMemcpyHostToDevice, s));
+  FC_CHECK_HIP(hipStreamSynchronize(s));      // `e` is a stack temporary (test entry point)
+  return fc_ln_reduce_grouped(tab, 1, D, s);
 }
 extern "C" int fc_k_gemm(int32_t impl, int32_t kind, int32_t dt_in, int32_t dt_out, const void* A, const void* Bm, void* C, int32_t M, int32_t N,
                          int32_t K, const float* bias, int32_t gelu, void* stream) {

@@ -236,6 +236,11 @@ int fc_k_layernorm_fwd(int32_t dt, const void* x, const float* g, const float* b
                        int32_t M, int32_t D, float eps, void* stream);
 int fc_k_layernorm_bwd(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
                        const void* res, void* dx, float* dg, float* db, int32_t M, int32_t D, void* stream);
+/* the in-model form of the backward: per-block dgamma / dbeta partial rows in `partial` (fc_k_layernorm_partial_floats floats) and one
+ * grouped reduction that ADDS into dg / db, instead of atomics (test entry point: synchronises the stream once) */
+size_t fc_k_layernorm_partial_floats(int32_t M, int32_t D);
+int fc_k_layernorm_bwd_partial(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
+                               const void* res, void* dx, float* dg, float* db, int32_t M, int32_t D, float* partial, void* stream);
 /* kind: 0 NT (C=A.W^T, A[M,K], W[N,K]); 1 NN (C=A.W, A[M,K], W[K,N]); 2 TN (C=A^T.B, A[K,M], B[K,N]).
  * impl: 0 generic VALU, 1 MFMA bf16 (returns 1 when the shape is unsupported). dtC: type of C. bias may be NULL. */
 int fc_k_gemm(int32_t impl, int32_t kind, int32_t dt_in, int32_t dt_out, const void* A, const void* B, void* C, int32_t M,

@@ -72,6 +72,14 @@ def test_layernorm(prec, M, D):
     e = maxerr(dx, dx_ref + res); assert e <= tol * amax(dx_ref + res), f"dx err {e}"
     e = maxerr(dg, dg_ref); assert e <= 1e-4 * amax(dg_ref), f"dg err {e}"
     e = maxerr(db, db_ref); assert e <= 1e-4 * amax(db_ref), f"db err {e}"
+    # the in-model form: per-block partial rows + grouped reduction (no atomics on the hot path)
+    dx2 = torch.empty_like(xd); dg2 = torch.zeros(D, device="cuda"); db2 = torch.zeros(D, device="cuda")
+    part = torch.empty(int(lib.fc_k_layernorm_partial_floats(M, D)), device="cuda")
+    L().check(lib.fc_k_layernorm_bwd_partial(code, P(dyd), P(xd), P(mean), P(rstd), P(dev(gam)), P(resd), P(dx2), P(dg2), P(db2), M, D, P(part), S()))
+    torch.cuda.synchronize()
+    e = maxerr(dx2, dx_ref + res); assert e <= tol * amax(dx_ref + res), f"dx (partial form) err {e}"
+    e = maxerr(dg2, dg_ref); assert e <= 1e-4 * amax(dg_ref), f"dg (partial form) err {e}"
+    e = maxerr(db2, db_ref); assert e <= 1e-4 * amax(db_ref), f"db (partial form) err {e}"
 
 
 @pytest.mark.parametrize("impl", [0, 1])
