@@ -76,10 +76,12 @@ template <typename T> struct Io;
 template <> struct Io<float> {
   static __device__ inline float ld(const float* p, size_t i) { return p[i]; }
   static __device__ inline void st(float* p, size_t i, float v) { p[i] = v; }
+  static __device__ inline float rt(float v) { return v; }              // the value as it reads back after a store
 };
 template <> struct Io<bf16_t> {
   static __device__ inline float ld(const bf16_t* p, size_t i) { return bf2f(p[i]); }
   static __device__ inline void st(bf16_t* p, size_t i, float v) { p[i] = f2bf(v); }
+  static __device__ inline float rt(float v) { return bf2f(f2bf(v)); }
 };
 
 // ---------------------------------------------------------------- wave64 reductions (DPP/shuffle, no LDS)

@@ -103,7 +103,7 @@ template <typename T, int CH>      // CH: 8-column chunks per lane (1: D <= 512)
 __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ g, const T* res, T* dx,
                                                   float* __restrict__ dg, float* __restrict__ db, int M, int D, int rows_per_block,
-                                                  float* __restrict__ partial) {
+                                                  float* __restrict__ partial, T* dx_scaled, const float* __restrict__ rowscale, int rows_per_sample) {
   extern __shared__ float red_dyn[];   // [2][4][D]: sized by the launch, so that narrow models keep many blocks per CU
 #define RED(a, w, i) red_dyn[((a) * 4 + (w)) * D + (i)]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -170,6 +170,13 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = rs[q] * (d[q][t][i] * gg[t][i] - m1 - xh[q][t][i] * m2) + (res ? rr[q][t][i] : 0.f);
           V8<T>::st(dx + (size_t)row[q] * D + c * 8, o);
+          if (dx_scaled) {      // drop-path: the consumer of this gradient wants it times the per-sample multiplier (of the STORED value)
+            const float sc = rowscale[row[q] / rows_per_sample];
+            float os[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) os[i] = Io<T>::rt(o[i]) * sc;
+            V8<T>::st(dx_scaled + (size_t)row[q] * D + c * 8, os);
+          }
         }
       }
     }
@@ -301,18 +308,53 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const T* __restrict__ dy, const 
 
 int fc_layernorm_bwd_partial_blocks(int M) { return fc_cdiv(M, 16); }
 
+// plain per-row scaled copy (drop-path backward where no LayerNorm backward produces the operand): 16-byte accesses when possible
+template <typename T>
+__global__ void __launch_bounds__(256) k_rowscale_v(const T* __restrict__ src, T* __restrict__ dst, const float* __restrict__ rs, int rows_per_sample,
+                                                    size_t n8, int D8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float v[8];
+    V8<T>::ld(src + i * 8, v);
+    const float sc = rs[(i / D8) / rows_per_sample];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= sc;
+    V8<T>::st(dst + i * 8, v);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_rowscale_s(const T* __restrict__ src, T* __restrict__ dst, const float* __restrict__ rs, int rows_per_sample,
+                                                    size_t n, int D) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    Io<T>::st(dst, i, Io<T>::ld(src, i) * rs[(i / D) / rows_per_sample]);
+}
+int fc_rowscale(int dt, const void* src, void* dst, const float* rs, int rows_per_sample, int M, int D, hipStream_t s) {
+  const size_t n = (size_t)M * D;
+  if (n == 0) return 0;
+  if ((D & 7) == 0 && !(((uintptr_t)src | (uintptr_t)dst) & 15)) {
+    const size_t n8 = n / 8;
+    const int grid = (int)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+    DISPATCH_DT(dt, hipLaunchKernelGGL(k_rowscale_v<T>, dim3(grid), dim3(256), 0, s, (const T*)src, (T*)dst, rs, rows_per_sample, n8, D / 8));
+  } else {
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    DISPATCH_DT(dt, hipLaunchKernelGGL(k_rowscale_s<T>, dim3(grid), dim3(256), 0, s, (const T*)src, (T*)dst, rs, rows_per_sample, n, D));
+  }
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
 int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res,
-                     void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial) {
+                     void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial, void* dx_scaled, const float* rowscale,
+                     int rows_per_sample) {
   if (FC_ABLATED("ln")) return 0;
   if (M <= 0) return 0;
   if (ln_vec_ok(dy, x, dx, res, D) && !((uintptr_t)g & 15)) {
     const int rpb = 16;
     if (D <= 512) {
       DISPATCH_DT(dt, hipLaunchKernelGGL((k_ln_bwd_v<T, 1>), dim3(fc_cdiv(M, rpb)), dim3(256), sizeof(float) * 8 * D, s, (const T*)dy, (const T*)x, mean,
-                                         rstd, g, (const T*)res, (T*)dx, dg, db, M, D, rpb, partial));
+                                         rstd, g, (const T*)res, (T*)dx, dg, db, M, D, rpb, partial, (T*)dx_scaled, rowscale, rows_per_sample));
     } else {
       DISPATCH_DT(dt, hipLaunchKernelGGL((k_ln_bwd_v<T, LNV_MAXC>), dim3(fc_cdiv(M, rpb)), dim3(256), sizeof(float) * 8 * D, s, (const T*)dy, (const T*)x,
-                                         mean, rstd, g, (const T*)res, (T*)dx, dg, db, M, D, rpb, partial));
+                                         mean, rstd, g, (const T*)res, (T*)dx, dg, db, M, D, rpb, partial, (T*)dx_scaled, rowscale, rows_per_sample));
     }
     FC_LAUNCH_CHECK();
     return partial ? 1 : 0;   // 1: dg/db are pending in `partial` (caller queues the grouped reduction)
@@ -321,6 +363,7 @@ int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, c
   DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(fc_cdiv(M, LNB_ROWS)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, g,
                                      (const T*)res, (T*)dx, dg, db, M, D));
   FC_LAUNCH_CHECK();
+  if (dx_scaled) return fc_rowscale(dt, dx, dx_scaled, rowscale, rows_per_sample, M, D, s);
   return 0;
 }
 

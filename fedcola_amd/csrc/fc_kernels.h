@@ -23,8 +23,12 @@ struct FcLnReduce {
   int nblocks, D;
 };
 int fc_layernorm_bwd_partial_blocks(int M);
+// dx_scaled (optional): a second output dx * rowscale[row / rows_per_sample] (drop-path: the next consumer's operand), written by the
+// same pass instead of a separate scaled copy
 int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
-                     const void* res, void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial = nullptr);
+                     const void* res, void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial = nullptr,
+                     void* dx_scaled = nullptr, const float* rowscale = nullptr, int rows_per_sample = 1);
+int fc_rowscale(int dt, const void* src, void* dst, const float* rs, int rows_per_sample, int M, int D, hipStream_t s);
 int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s);
 
 // ---- image embedding (K1): patches[B*np, C*P*P] (conv-weight order), cls rows, and backward pieces

@@ -417,8 +417,8 @@ struct Ctx {
   int n_more = 0;                              // flush_dw also orders the chunk after the other micro-batch chains' streams
   std::vector<FcLnReduce>* lnq = nullptr;      // non-null: LayerNorm dgamma/dbeta partials are queued likewise
   int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res, void* dx, float* dg,
-             float* db, int M, int D, float* partial) const {
-    int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, lnq ? partial : nullptr);
+             float* db, int M, int D, float* partial, void* dx_scaled = nullptr, const float* rowscale = nullptr, int rps = 1) const {
+    int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, lnq ? partial : nullptr, dx_scaled, rowscale, rps);
     if (r == 1) { lnq->push_back(FcLnReduce{partial, dg, db, fc_layernorm_bwd_partial_blocks(M), D}); return 0; }
     return r;
   }
@@ -468,22 +468,6 @@ struct Ctx {
     return fc_attn_bwd_generic(dt, qkv, o, dO, lse, delta, dqkv, B, N, H, d, scale, s);
   }
 };
-
-// scaled copy for drop-path backward: dst[m,:] = src[m,:] * rowscale[m / rows_per_sample]
-template <typename T>
-__global__ void __launch_bounds__(256) k_rowscale(const T* __restrict__ src, T* __restrict__ dst, const float* __restrict__ rs, int rows_per_sample,
-                                                  size_t n, int D) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    Io<T>::st(dst, i, Io<T>::ld(src, i) * rs[(i / D) / rows_per_sample]);
-}
-static int rowscale(int dt, const void* src, void* dst, const float* rs, int rows_per_sample, int M, int D, hipStream_t s) {
-  size_t n = (size_t)M * D;
-  int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-  if (dt == FC_F32) hipLaunchKernelGGL(k_rowscale<float>, dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, rs, rows_per_sample, n, D);
-  else hipLaunchKernelGGL(k_rowscale<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, rs, rows_per_sample, n, D);
-  FC_LAUNCH_CHECK();
-  return 0;
-}
 
 static const float* dp_ptr(const fc_model* m, const Ws& w, int tower, int layer, int branch) {
   if (!w.droppath) return nullptr;
@@ -840,25 +824,32 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
       continue;
     }
     // ---- MLP branch: x_{l+1} = xmid + s2 * (gact.W2^T + b2)
+    // drop-path: dm = dx * s2.  For every layer but the last, the LayerNorm backward that produced dx (norm1 of layer l+1) wrote the
+    // scaled copy as its second output; the last layer's dx comes from the head
     const float* s2 = dp_ptr(m, w, i, l, 1);
     const void* dm = dx;
-    if (s2) { FC_TRY(rowscale(c.dt, dx, L.gdm, s2, N, M, D, c.s)); dm = L.gdm; }
+    if (s2) {
+      if (l == cf.depth - 1) FC_TRY(fc_rowscale(c.dt, dx, L.gdm, s2, N, M, D, c.s));
+      dm = L.gdm;
+    }
     FC_TRY(linear_bwd_params(c, b.fc2, dm, L.gact, M, grads));
     { GemmEpi e; e.gelu_in = L.u; e.gelu_saved_grad = (c.dt == FC_BF16); FC_TRY(c.gemm_dx(dm, c.W(b.fc2.w), L.gdu, M, D, Hd, e)); }                  // du = (dm.W2) * gelu'(u)
     FC_TRY(linear_bwd_params(c, b.fc1, L.gdu, L.h2, M, grads));
     const size_t lnp = (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D;
     { GemmEpi e; FC_TRY(c.gemm_dx(L.gdu, c.W(b.fc1.w), t.dh, M, Hd, D, e)); }                                  // dh2
-    FC_TRY(c.ln_bwd(t.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, dx, L.gxmid, grads + b.n2w, grads + b.n2b, M, D, t.ln_partial + (2 * l + 1) * lnp));
-    // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp)
+    // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp); da = gxmid * s1 comes out of the same LayerNorm-backward pass
     const float* s1 = dp_ptr(m, w, i, l, 0);
-    const void* da = L.gxmid;
-    if (s1) { FC_TRY(rowscale(c.dt, L.gxmid, L.gda, s1, N, M, D, c.s)); da = L.gda; }
+    FC_TRY(c.ln_bwd(t.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, dx, L.gxmid, grads + b.n2w, grads + b.n2b, M, D, t.ln_partial + (2 * l + 1) * lnp,
+                    s1 ? L.gda : nullptr, s1, N));
+    const void* da = s1 ? (const void*)L.gda : (const void*)L.gxmid;
     FC_TRY(linear_bwd_params(c, b.proj, da, L.o, M, grads));
     { GemmEpi e; FC_TRY(c.gemm_dx(da, c.W(b.proj.w), t.dO, M, D, D, e)); }
     FC_TRY(c.attn_bwd(L.qkv, L.o, t.dO, L.lse, t.delta, L.gdqkv, B, N));
     FC_TRY(linear_bwd_params(c, b.qkv, L.gdqkv, L.h1, M, grads));
     { GemmEpi e; FC_TRY(c.gemm_dx(L.gdqkv, c.W(b.qkv.w), t.dh, M, 3 * D, D, e)); }                             // dh1
-    FC_TRY(c.ln_bwd(t.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, L.gxmid, t.gx[l], grads + b.n1w, grads + b.n1b, M, D, t.ln_partial + (2 * l) * lnp));
+    const float* s2_below = l > 0 ? dp_ptr(m, w, i, l - 1, 1) : nullptr;      // the layer below wants gx[l] * s2(l-1) as its dm
+    FC_TRY(c.ln_bwd(t.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, L.gxmid, t.gx[l], grads + b.n1w, grads + b.n1b, M, D, t.ln_partial + (2 * l) * lnp,
+                    s2_below ? t.L[l - 1].gdm : nullptr, s2_below, N));
     if (phase == PH_ALL && dw_flush_here(l)) FC_TRY(flush_dw(c));   // this chunk's weight gradients start now
   }
   if (phase == PH_WGRAD_EMBED) {
