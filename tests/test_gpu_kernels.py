@@ -182,3 +182,18 @@ def test_cast_bf16_rne():
     L().check(L().lib().fc_k_cast(1, P(dev(x)), P(y), 1000, S()))
     torch.cuda.synchronize()
     assert torch.equal(y.cpu(), x.to(torch.bfloat16))
+
+
+def test_weight_stationary_gemm_opt_in_path(tmp_path):
+    """The K = 384 weight-stationary kernels (fc_gemm_ws.hip) are opt-in (FC_GEMM_WS=1, read once per process): run the GEMM and
+    model parity tests in a child process with the switch on, so that the path stays correct although the default step does not
+    take it (faster stand-alone on the N = 1536 shapes, not inside the multi-stream step)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FC_GEMM_WS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_kernels.py"), "-k", "gemm",
+                        os.path.join(root, "tests", "test_gpu_bf16_parity.py") + "::test_vit_s_b64_bf16_layer_by_layer"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
