@@ -193,7 +193,7 @@ def test_weight_stationary_gemm_opt_in_path(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FC_GEMM_WS="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_kernels.py"), "-k", "gemm",
-                        os.path.join(root, "tests", "test_gpu_bf16_parity.py") + "::test_vit_s_b64_bf16_layer_by_layer"],
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_kernels.py"),
+                        os.path.join(root, "tests", "test_gpu_bf16_parity.py"), "-k", "test_gemm or layer_by_layer"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
