@@ -717,8 +717,8 @@ extern "C" int fc_forward(const fc_model_t* m, const float* params, const void* 
 
 // ---------------------------------------------------------------- backward
 static int dw_flush_every() {
-  static int v = getenv("FC_DW_FLUSH") ? atoi(getenv("FC_DW_FLUSH")) : 2;
-  return v > 0 ? v : 2;
+  static int v = getenv("FC_DW_FLUSH") ? atoi(getenv("FC_DW_FLUSH")) : 4;    // round-2 sweep (ms/step): 1: 6.2, 2: 5.32, 3: 5.28, 4: 5.19, 6: 5.25
+  return v > 0 ? v : 4;
 }
 // flush after layer l?  (phase 1 would make the last, un-overlapped chunk the smallest -- layer 0 + embedding -- but
 // measured 2 % slower than phase 0 on the ViT-S step)

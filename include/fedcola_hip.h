@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 1
+#define FC_ABI_VERSION 2   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial */
 
 enum { FC_PREC_FP32 = 0, FC_PREC_BF16 = 1 };
 enum { FC_TASK_NONE = 0, FC_TASK_CLS = 1, FC_TASK_RTV = 2 };

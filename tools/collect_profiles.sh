@@ -1,34 +1,45 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun) from the repo root: collects everything profiles/rNN/ holds.  usage: tools/collect_profiles.sh r01
-R=${1:-r01}
+# Run on the GPU box (via gpurun) from the repo root: collects everything profiles/rNN/ holds.  usage: tools/collect_profiles.sh r02
+R=${1:-r02}
 OUT=gpurun_out/$R
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-# 1. the bench line (default flags: N=1, cpu_baseline, roofline)
-timeout 600 python bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.txt"
-# 2. kernel trace + stats of the same workload
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --no-cpu-baseline > "$OUT/trace.log" 2>&1
-python tools/prof_summary.py "$OUT/trace" 35 40 > "$OUT/bench_summary.txt" 2>&1
-cp "$OUT"/trace/bench_kernel_stats.csv "$OUT/bench_kernel_stats.csv" 2>/dev/null
-cp "$OUT"/trace/bench_domain_stats.csv "$OUT/bench_domain_stats.csv" 2>/dev/null
-# 2b. the roofline kernel alone (the probe bench.py times with HIP events): its average duration in this summary is the one to compare
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/gtrace" -o g -- python3 tools/gemm_bench.py 30 "NT fc1" > "$OUT/gtrace.log" 2>&1
-cp "$OUT"/gtrace/g_kernel_stats.csv "$OUT/gemm_fc1_kernel_stats.csv" 2>/dev/null
-# 3. counters of the dominant kernel, one counter set per pass
+ROOF="1,6304,384,1536"          # bench.py ROOF_KIND, ROOF_M, ROOF_N, ROOF_K: the NN dX GEMM at its in-model shape
+# 3. counters of the roofline kernel first (bench.py reads roofline_pmc.json), one counter set per pass, kernel-trace only
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" SQ_LDS_BANK_CONFLICT; do
   tag=$(echo $c | tr ' ' '_')
-  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$tag" -o g -- python3 tools/gemm_bench.py 5 "NT fc1" > "$OUT/pmc_$tag.log" 2>&1
-  cp "$OUT/pmc_$tag/g_counter_collection.csv" "$OUT/gemm_fc1_pmc_$tag.csv" 2>/dev/null
+  GEMM_SHAPES="$ROOF" timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "/tmp/pmc_$tag" -o g -- python3 tools/gemm_bench.py 8 > "$OUT/pmc_$tag.log" 2>&1
+  cp /tmp/pmc_$tag/g_counter_collection.csv "$OUT/roofline_pmc_$tag.csv" 2>/dev/null || find /tmp/pmc_$tag -name "*counter_collection.csv" -exec cp {} "$OUT/roofline_pmc_$tag.csv" \;
 done
+mkdir -p profiles/$R
+python tools/roofline_pmc.py profiles/$R /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES_GRBM_GUI_ACTIVE /tmp/pmc_SQ_LDS_BANK_CONFLICT > "$OUT/roofline_pmc_print.txt" 2>&1
+cp profiles/$R/roofline_pmc.json "$OUT/roofline_pmc.json"
+# 1. the bench line (default flags: N=1, cpu_baseline, roofline with the PMC traffic just measured, dropout-0.1 line)
+timeout 900 python bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.txt"
+# 1b. the multi-rank path on this one device (two ranks on cuda:0, gloo for the all-reduce: RCCL refuses two ranks per device)
+FC_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 30 --warmup 5 --no-roofline > "$OUT/bench_2ranks_one_device.json" 2> "$OUT/bench_2ranks_stderr.txt"
+# 2. kernel trace + stats of the same workload (35 steps)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trace -o bench -- python3 bench.py --no-cpu-baseline --no-dropout-line --no-roofline --steps 30 --warmup 5 > "$OUT/trace.log" 2>&1
+python tools/prof_summary.py /tmp/trace 35 40 > "$OUT/bench_summary.txt" 2>&1
+find /tmp/trace -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
+# 2b. the roofline kernel alone: device-side duration to compare with roofline.us_per_launch (HIP events inside bench.py)
+GEMM_SHAPES="$ROOF" timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gtrace -o g -- python3 tools/gemm_bench.py 30 > "$OUT/gtrace.log" 2>&1
+find /tmp/gtrace -name "*kernel_stats.csv" -exec cp {} "$OUT/roofline_kernel_stats.csv" \;
+python tools/ktrace.py /tmp/gtrace > "$OUT/roofline_kernel_trace.txt" 2>&1
+# 2c. every GEMM shape of a layer + the non-GEMM kernels, stand-alone (device-side durations)
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/gall -o g -- python3 tools/gemm_bench.py 20 > /dev/null 2>&1; python tools/ktrace.py /tmp/gall > "$OUT/gemm_shapes_ktrace.txt" 2>&1
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/kb -o g -- python3 tools/kernel_bench.py 20 > /dev/null 2>&1; python tools/ktrace.py /tmp/kb > "$OUT/kernels_ktrace.txt" 2>&1
+# 2d. GPU time of the step's phases, no profiler (tools build)
+timeout 200 python tools/step_phases.py 40 2>/dev/null > "$OUT/step_phases.txt"
 # 4. whole-step fabric traffic (separate passes)
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/step_$c" -o s -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > "$OUT/step_$c.log" 2>&1
-  python tools/pmc_sum.py "$OUT/step_$c" 5 > "$OUT/step_pmc_$c.txt" 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "/tmp/step_$c" -o s -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-dropout-line > "$OUT/step_$c.log" 2>&1
+  python tools/pmc_sum.py "/tmp/step_$c" 5 > "$OUT/step_pmc_$c.txt" 2>&1
 done
-# 5. retrieval row
+# 5. widened rows
 timeout 200 python tools/retrieval_bench.py 5 2>/dev/null > "$OUT/retrieval_bench.txt"
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rtrace" -o r -- python3 tools/retrieval_bench.py 3 > "$OUT/rtrace.log" 2>&1
-python tools/prof_summary.py "$OUT/rtrace" 4 6 > "$OUT/retrieval_summary.txt" 2>&1
-rm -rf "$OUT"/trace/*trace.csv "$OUT"/gtrace "$OUT"/rtrace "$OUT"/pmc_* "$OUT"/step_FETCH_SIZE "$OUT"/step_WRITE_SIZE "$OUT"/*.log
+timeout 300 python tools/cream_bench.py 2>/dev/null > "$OUT/cream_bench.txt"
+timeout 300 python tools/loader_bench.py 1024 2>/dev/null > "$OUT/loader_bench.txt"
+rm -f "$OUT"/*.log
 ls -la "$OUT"
 cat "$OUT/bench_line.json"
