@@ -704,13 +704,7 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, float* __r
     float4 pp = ((float4*)p)[i], gg = ((float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
     float* P = (float*)&pp; float* G = (float*)&gg; float* Mm = (float*)&mm; float* V = (float*)&vv;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float pk = P[k] * decay;
-      Mm[k] = Mm[k] + (G[k] - Mm[k]) * (1.0f - beta1);            // exp_avg.lerp_(grad, 1-beta1)
-      V[k] = V[k] * beta2 + (1.0f - beta2) * G[k] * G[k];
-      float denom = sqrtf(V[k]) * inv_bc2_sqrt + eps;
-      P[k] = pk - step_size * (Mm[k] / denom);
-    }
+    for (int k = 0; k < 4; ++k) fc_adamw_elem(P[k], G[k], Mm[k], V[k], decay, beta1, beta2, eps, step_size, inv_bc2_sqrt);
     ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
     if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (shadow) {
@@ -723,15 +717,54 @@ int fc_adamw(float* p, float* g, float* m, float* v, size_t n, float lr, float b
              void* shadow_bf16, int zero_grad, hipStream_t s) {
   if (FC_ABLATED("adamw")) return 0;
   FC_REQUIRE(n % 4 == 0 && ((uintptr_t)p % 16 == 0), "adamw: buffer must be 16B aligned and a multiple of 4 elements");
-  double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  float step_size = (float)((double)lr / bc1);
-  float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-  float decay = (float)(1.0 - (double)lr * (double)wd);
+  const FcAdamW o = fc_adamw_consts(lr, beta1, beta2, eps, wd, step);
+  const float step_size = o.step_size, inv_bc2_sqrt = o.inv_bc2_sqrt, decay = o.decay;
   size_t n4 = n / 4;
   int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, s, p, g, m, v, n, decay, beta1, beta2, eps, step_size, inv_bc2_sqrt,
                      (bf16_t*)shadow_bf16, zero_grad);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
+FcAdamW fc_adamw_consts(float lr, float beta1, float beta2, float eps, float wd, int step) {
+  FcAdamW o;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  o.step_size = (float)((double)lr / bc1);
+  o.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  o.decay = (float)(1.0 - (double)lr * (double)wd);
+  o.beta1 = beta1; o.beta2 = beta2; o.eps = eps;
+  return o;
+}
+// one workgroup per chunk; float4 accesses where the chunk is 16-B aligned (every tensor of the models here is), scalar otherwise
+__global__ void __launch_bounds__(256) k_adamw_chunks(const FcProxChunk* __restrict__ chunks, FcAdamW o) {
+  const FcProxChunk c = chunks[blockIdx.x];
+  float* p = o.p + c.offset; float* g = o.g0 + c.offset; float* m = o.m + c.offset; float* v = o.v + c.offset;
+  if (((c.offset | c.n) & 3) == 0) {
+    for (int i = threadIdx.x; i < c.n / 4; i += 256) {
+      float4 pp = ((float4*)p)[i], gg = ((float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+      float* P = (float*)&pp; float* G = (float*)&gg; float* Mm = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fc_adamw_elem(P[k], G[k], Mm[k], V[k], o.decay, o.beta1, o.beta2, o.eps, o.step_size, o.inv_bc2_sqrt);
+      ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+      if (o.shadow) {
+        ushort4 sh; sh.x = f2bf(P[0]); sh.y = f2bf(P[1]); sh.z = f2bf(P[2]); sh.w = f2bf(P[3]);
+        ((ushort4*)(o.shadow + c.offset))[i] = sh;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < c.n; i += 256) {
+      float pp = p[i], mm = m[i], vv = v[i];
+      fc_adamw_elem(pp, g[i], mm, vv, o.decay, o.beta1, o.beta2, o.eps, o.step_size, o.inv_bc2_sqrt);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+      if (o.shadow) o.shadow[c.offset + i] = f2bf(pp);
+    }
+  }
+}
+int fc_adamw_chunks(const FcProxChunk* chunks_dev, int nchunks, const FcAdamW& o, hipStream_t s) {
+  if (nchunks <= 0 || FC_ABLATED("adamw")) return 0;
+  hipLaunchKernelGGL(k_adamw_chunks, dim3(nchunks), dim3(256), 0, s, chunks_dev, o);
   FC_LAUNCH_CHECK();
   return 0;
 }

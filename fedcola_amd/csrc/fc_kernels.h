@@ -59,6 +59,33 @@ int fc_ce_fwd_bwd(const float* logits, const int64_t* y, int B, int C, float* lo
 // ---- optimizer (K13): torch.optim.AdamW semantics; optionally refreshes the low-precision shadow and zeroes grads
 int fc_adamw(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd,
              int step, void* shadow_bf16, int zero_grad, hipStream_t s);
+// AdamW constants of one optimizer step + the flat buffers they apply to (same element offsets in all of them).  Used by the
+// stand-alone kernels and by the weight-gradient GEMM's fused epilogue (fc_gemm_tn_grouped with `opt`): one formula, one rounding
+// sequence (fc_adamw_elem), so the fused and the separate optimizer produce the same bits from the same gradient.
+struct FcAdamW {
+  float* g0 = nullptr;         // gradients (base of the flat buffer; element index = pointer - g0)
+  float* p = nullptr;          // parameters
+  float* m = nullptr;          // exp_avg
+  float* v = nullptr;          // exp_avg_sq
+  bf16_t* shadow = nullptr;    // bf16 compute weights for the next step (may be null)
+  float decay, beta1, beta2, eps, step_size, inv_bc2_sqrt;
+};
+FcAdamW fc_adamw_consts(float lr, float beta1, float beta2, float eps, float wd, int step);
+#ifdef __HIPCC__
+__device__ __forceinline__ void fc_adamw_elem(float& p, float g, float& m, float& v, float decay, float beta1, float beta2, float eps, float step_size,
+                                              float inv_bc2_sqrt) {
+#pragma clang fp contract(off)   // every product and sum rounded on its own, wherever this is inlined: the same bits from every kernel
+  const float pk = p * decay;
+  m = m + (g - m) * (1.0f - beta1);            // exp_avg.lerp_(grad, 1-beta1)
+  v = v * beta2 + (1.0f - beta2) * g * g;
+  const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+  p = pk - step_size * (m / denom);
+}
+#endif
+// AdamW over a table of chunks (<= FC_PROX_CHUNK consecutive elements each; FcProxChunk.seg unused): everything the fused epilogue
+// does not cover, in one launch
+struct FcProxChunk;
+int fc_adamw_chunks(const FcProxChunk* chunks_dev, int nchunks, const FcAdamW& o, hipStream_t s);
 int fc_cast(int dt_out, const float* src, void* dst, size_t n, hipStream_t s);
 // W_eff = W + s*A (K9) into dst (type dt)
 int fc_reparam_fold(int dt, const float* W, const float* A, const float* scale, void* dst, size_t n, hipStream_t s);
@@ -109,7 +136,13 @@ struct FcTnProblem {
   int tile_start, tiles_n;
 };
 int fc_gemm_tn_grouped_supported(const FcTnProblem& p);
-int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s);
+// 128 x 384 tiles for problems whose N (the linear's `in`) is a multiple of 384 (fc_gemm_dw.hip): same table format, own tile numbering
+int fc_gemm_dw_wide_supported(const FcTnProblem& p);
+int fc_gemm_dw_wide_tiles(const FcTnProblem& p, int* tiles_n);
+int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s, const struct FcAdamW* opt = nullptr);
+// opt != null: the epilogue also takes the AdamW step of every element it produced (dW tiles and the bias gradients), so the
+// optimizer needs no pass of its own over the linears' weights; the gradient is still stored
+int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s, const FcAdamW* opt = nullptr);
 
 // ---- attention (K5).  qkv: [B,N,3,H,d] row-major (= the qkv GEMM output [B*N, 3*H*d]); o: [B,N,H*d]; lse: [B,H,N]
 int fc_attn_fwd_generic(int dt, const void* qkv, void* o, float* lse, int B, int N, int H, int d, float scale, hipStream_t s);

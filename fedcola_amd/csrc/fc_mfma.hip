@@ -491,7 +491,11 @@ k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B
 // All dW = dY^T . X products of a backward pass (every linear of every layer of both towers) in ONE launch, each output
 // tile owned by exactly one workgroup that walks the whole reduction: no split-K, no atomics, bitwise reproducible.
 // The bias gradient (column sums of dY) falls out of the A-operand staging registers of the tile_n == 0 workgroups.
-__global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* __restrict__ probs, int nprob) {
+// OPT: the epilogue also takes the AdamW step of the elements it produced (parameters, moments, bf16 shadow at the same element
+// offsets as the gradient): the optimizer's pass over the linears' weights -- 86 % of the parameters, 7 HBM streams -- disappears into
+// the weight-gradient launches that run under the backward.
+template <bool OPT>
+__global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -522,21 +526,66 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* _
       float sum = 0.f;
 #pragma unroll
       for (int kg = 0; kg < 16; ++kg) sum += R[kg * 128 + tid];
-      if (m0 + tid < M) P.bias_grad[m0 + tid] = sum;
+      if (m0 + tid < M) {
+        P.bias_grad[m0 + tid] = sum;
+        if (OPT) {
+          const size_t idx = (size_t)(P.bias_grad + m0 + tid - o.g0);
+          float pp = o.p[idx], mm = o.m[idx], vv = o.v[idx];
+          fc_adamw_elem(pp, sum, mm, vv, o.decay, o.beta1, o.beta2, o.eps, o.step_size, o.inv_bc2_sqrt);
+          o.p[idx] = pp; o.m[idx] = mm; o.v[idx] = vv;
+          if (o.shadow) o.shadow[idx] = f2bf(pp);
+        }
+      }
     }
   }
   lds_barrier();
   float* Cs = (float*)smem;
   acc_to_lds(Cs, acc, wm, wn, lane);
   lds_barrier();
+  if (!OPT) {
 #pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      int row = (tid >> 4) + 16 * p, c8 = (tid & 15) * 8;
+      int m = m0 + row, n = n0 + c8;
+      if (m < M && n < N) {
+        float* dst = P.C + (size_t)m * P.ldc + n;
+        *(float4*)dst = *(const float4*)(Cs + row * CS_LD + c8);
+        *(float4*)(dst + 4) = *(const float4*)(Cs + row * CS_LD + c8 + 4);
+      }
+    }
+    return;
+  }
+  // 16 consecutive threads own one 512-B row segment of each stream; two rows (12 x 16-B loads) in flight per thread
+#pragma unroll 2
   for (int p = 0; p < 8; ++p) {
-    int row = (tid >> 4) + 16 * p, c8 = (tid & 15) * 8;
-    int m = m0 + row, n = n0 + c8;
+    const int row = (tid >> 4) + 16 * p, c8 = (tid & 15) * 8;
+    const int m = m0 + row, n = n0 + c8;
     if (m < M && n < N) {
       float* dst = P.C + (size_t)m * P.ldc + n;
-      *(float4*)dst = *(const float4*)(Cs + row * CS_LD + c8);
-      *(float4*)(dst + 4) = *(const float4*)(Cs + row * CS_LD + c8 + 4);
+      const size_t idx = (size_t)(dst - o.g0);
+      float4 g[2], pp[2], mm[2], vv[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        pp[h] = *(const float4*)(o.p + idx + 4 * h);
+        mm[h] = *(const float4*)(o.m + idx + 4 * h);
+        vv[h] = *(const float4*)(o.v + idx + 4 * h);
+        g[h] = *(const float4*)(Cs + row * CS_LD + c8 + 4 * h);
+      }
+      bf16_t sh[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float* Pp = (float*)&pp[h]; float* G = (float*)&g[h]; float* Mm = (float*)&mm[h]; float* V = (float*)&vv[h];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          fc_adamw_elem(Pp[k], G[k], Mm[k], V[k], o.decay, o.beta1, o.beta2, o.eps, o.step_size, o.inv_bc2_sqrt);
+          sh[4 * h + k] = f2bf(Pp[k]);
+        }
+        *(float4*)(dst + 4 * h) = g[h];
+        *(float4*)(o.p + idx + 4 * h) = pp[h];
+        *(float4*)(o.m + idx + 4 * h) = mm[h];
+        *(float4*)(o.v + idx + 4 * h) = vv[h];
+      }
+      if (o.shadow) *(uint4*)(o.shadow + idx) = *(const uint4*)sh;
     }
   }
 }
@@ -545,12 +594,17 @@ int fc_gemm_tn_grouped_supported(const FcTnProblem& p) {
   return !((p.M & 7) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) ||
            ((uintptr_t)p.C & 15));
 }
-int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s) {
+int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s, const FcAdamW* opt) {
   if (nprob <= 0 || total_tiles <= 0) return 0;
   const int lds = BM * CS_LD * 4;
   static bool done = false;
-  if (!done) { FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_tn_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); done = true; }
-  hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(total_tiles), dim3(256), lds, s, probs_dev, nprob);
+  if (!done) {
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_tn_grouped<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_tn_grouped<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    done = true;
+  }
+  if (opt) hipLaunchKernelGGL(k_gemm_tn_grouped<true>, dim3(total_tiles), dim3(256), lds, s, probs_dev, nprob, *opt);
+  else hipLaunchKernelGGL(k_gemm_tn_grouped<false>, dim3(total_tiles), dim3(256), lds, s, probs_dev, nprob, FcAdamW());
   FC_LAUNCH_CHECK();
   return 0;
 }

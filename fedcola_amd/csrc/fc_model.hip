@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/fedcola_hip.h"
@@ -56,6 +57,10 @@ struct fc_model {
   // address with other contents)
   mutable void* tables_dev = nullptr;
   mutable size_t tables_bytes = 0;
+  // fused optimizer (fc_client_step): which segments the weight-gradient epilogue steps, and the chunk table of everything else
+  mutable std::vector<char> fused_host;
+  mutable void* rest_dev = nullptr;
+  mutable int rest_chunks = 0;
   // the two towers are independent until the loss: the text tower runs on a side stream, forked/joined with events
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -67,6 +72,7 @@ struct fc_model {
   mutable hipEvent_t ev_mb_join[3] = {nullptr, nullptr, nullptr};
   ~fc_model() {
     if (tables_dev) (void)hipFree(tables_dev);
+    if (rest_dev) (void)hipFree(rest_dev);
     if (ev_dw_in) (void)hipEventDestroy(ev_dw_in);
     for (int k = 0; k < 3; ++k) {
       if (ev_dw_in2[k]) (void)hipEventDestroy(ev_dw_in2[k]);
@@ -416,6 +422,8 @@ struct Ctx {
   bool no_wgrad = false;                       // micro-batch slice: the full-batch weight gradients are queued by the driver
   int n_more = 0;                              // flush_dw also orders the chunk after the other micro-batch chains' streams
   std::vector<FcLnReduce>* lnq = nullptr;      // non-null: LayerNorm dgamma/dbeta partials are queued likewise
+  const FcAdamW* fopt = nullptr;               // non-null: the grouped weight-gradient launches also take the AdamW step of what they produce
+  std::vector<char>* fused_seg = nullptr;      // ... and the segments they cover are flagged here
   int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res, void* dx, float* dg,
              float* db, int M, int D, float* partial, void* dx_scaled = nullptr, const float* rowscale = nullptr, int rps = 1) const {
     int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, lnq ? partial : nullptr, dx_scaled, rowscale, rps);
@@ -717,8 +725,11 @@ extern "C" int fc_forward(const fc_model_t* m, const float* params, const void* 
 
 // ---------------------------------------------------------------- backward
 static int dw_flush_every() {
-  static int v = getenv("FC_DW_FLUSH") ? atoi(getenv("FC_DW_FLUSH")) : 4;    // round-2 sweep (ms/step): 1: 6.2, 2: 5.32, 3: 5.28, 4: 5.19, 6: 5.25
-  return v > 0 ? v : 4;
+  // round-2 sweeps (ms/step, one box each).  128x128 dW tiles: 1: 6.2, 2: 5.32, 3: 5.28, 4: 5.19, 6: 5.25.  128x384 tiles (whole CUs): 3: 5.32,
+  // 4: 5.00, 5: 5.11, 6: 4.93, 8: 5.18, 12 (no overlap with the backward at all): 4.97 -- overlapping the weight gradients with
+  // the backward buys 1 %: the backward is throughput-bound, what runs beside it slows it by about what it saves
+  static int v = getenv("FC_DW_FLUSH") ? atoi(getenv("FC_DW_FLUSH")) : 6;
+  return v > 0 ? v : 6;
 }
 // flush after layer l?  (phase 1 would make the last, un-overlapped chunk the smallest -- layer 0 + embedding -- but
 // measured 2 % slower than phase 0 on the ViT-S step)
@@ -743,8 +754,16 @@ static int flush_dw(const Ctx& c) {
   const size_t beg = st.flushed, n = all.size() - beg;
   if (n == 0) return 0;
   FC_REQUIRE((int)all.size() <= st.max_probs, "internal: too many deferred weight-gradient problems");
-  int tiles = 0;
-  for (size_t i = beg; i < all.size(); ++i) {
+  // problems whose `in` is a multiple of 384 take the 128x384-tile kernel, the rest the 128x128 one: two launches over two
+  // contiguous parts of the table, each with its own tile numbering
+  const size_t nw = (size_t)(std::stable_partition(all.begin() + beg, all.end(), [](const FcTnProblem& p) { return fc_gemm_dw_wide_supported(p) != 0; }) -
+                             (all.begin() + beg));
+  int tiles_w = 0, tiles = 0;
+  for (size_t i = beg; i < beg + nw; ++i) {
+    all[i].tile_start = tiles_w;
+    tiles_w += fc_gemm_dw_wide_tiles(all[i], &all[i].tiles_n);
+  }
+  for (size_t i = beg + nw; i < all.size(); ++i) {
     all[i].tile_start = tiles;
     all[i].tiles_n = fc_cdiv(all[i].N, 128);
     tiles += fc_cdiv(all[i].M, 128) * all[i].tiles_n;
@@ -765,7 +784,10 @@ static int flush_dw(const Ctx& c) {
     FC_CHECK_HIP(hipEventRecord(m->ev_dw_in2[k], m->mbs[k]));
     FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in2[k], 0));
   }
-  if (!FC_ABLATED("dw")) FC_TRY(fc_gemm_tn_grouped(st.dev + beg, (int)n, tiles, m->dws));
+  if (!FC_ABLATED("dw")) {
+    FC_TRY(fc_gemm_dw_wide(st.dev + beg, (int)nw, tiles_w, m->dws, c.fopt));
+    FC_TRY(fc_gemm_tn_grouped(st.dev + beg + nw, (int)(n - nw), tiles, m->dws, c.fopt));
+  }
   st.flushed = all.size();
   return 0;
 }
@@ -774,7 +796,13 @@ static int weight_grad(const Ctx& c, const void* dY, const void* X, int M, int o
   if (c.no_wgrad) return 0;
   if (c.defer) {
     FcTnProblem p{(const bf16_t*)dY, (const bf16_t*)X, dW, db, out, in, in, out, in, M, 0, 0};
-    if (fc_gemm_tn_grouped_supported(p)) { c.defer->push_back(p); return 0; }
+    if (fc_gemm_tn_grouped_supported(p)) {
+      c.defer->push_back(p);
+      if (c.fused_seg)
+        for (size_t k = 0; k < c.m->segs.size(); ++k)
+          if (c.m->segs[k].offset == dW - c.fopt->g0 || (db && c.m->segs[k].offset == db - c.fopt->g0)) (*c.fused_seg)[k] = 1;
+      return 0;
+    }
   }
   FC_TRY(c.gemm_dw(dY, X, dW, M, out, in));
   FC_TRY(fc_colsum(c.dt, dY, db, M, out, 1, c.s));
@@ -887,15 +915,16 @@ static int tower_reparam_grads(const Ctx& c, int i, float* grads) {
   return 0;
 }
 
-// The LAST weight-gradient chunk (layers 0..1 of the image tower + the patch embedding) starts when the whole backward is done and
+// The LAST weight-gradient chunk (the lowest layers of the image tower + the patch embedding) starts when the whole backward is done and
 // nothing is left to overlap it with -- except the optimizer: fc_client_step steps every parameter that does not depend on that
 // chunk first and waits for the chunk only before stepping the rest.
 struct LateDw {
   bool pending = false;
+  bool fused = false;             // fused optimizer: no segment waits for a chunk; the caller waits for ev_dw_out once, at the end
   std::vector<char> late_seg;     // per segment: its gradient is written by the last chunk
 };
 static int backward_impl(const fc_model* m, const float* params, const void* wc, const float* d_out_img, const float* d_out_txt, float* grads,
-                         Ws& w, hipStream_t s, LateDw* late = nullptr) {
+                         Ws& w, hipStream_t s, LateDw* late = nullptr, const FcAdamW* fopt = nullptr, std::vector<char>* fused_seg = nullptr) {
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
   std::vector<FcTnProblem> probs;
   std::vector<FcLnReduce> lnq;
@@ -910,6 +939,11 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     dwst.dev = probs_dev;
     dwst.max_probs = w.max_probs;
     c.dw = &dwst;
+    if (fopt) {
+      c.fopt = fopt;
+      c.fused_seg = fused_seg;
+      fused_seg->assign(m->segs.size(), 0);
+    }
   }
   c.lnq = &lnq;
   const bool run0 = m->tw[0].present && d_out_img, run1 = m->tw[1].present && d_out_txt;
@@ -944,7 +978,7 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
       }
       for (int k = 0; k < nmb; ++k) FC_TRY(tower_backward(ck[k], wk[k], 0, dk[k], grads, PH_EMBED));
       FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_EMBED));
-      if (late && dwst.flushed > 0 && dwst.flushed < probs.size()) {
+      if (late && !late->fused && dwst.flushed > 0 && dwst.flushed < probs.size()) {
         FC_CHECK_HIP(hipEventRecord(m->ev_dw_prev, m->dws));      // every chunk but the last
         late->late_seg.assign(m->segs.size(), 0);
         for (size_t q = dwst.flushed; q < probs.size(); ++q) {
@@ -989,7 +1023,8 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
   }
   if (!probs.empty()) {   // every chunk was launched by flush_dw; the main stream continues after the last one
     FC_CHECK_HIP(hipEventRecord(m->ev_dw_out, m->dws));
-    if (late && late->pending) FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_prev, 0));   // ... the caller waits for ev_dw_out itself
+    if (late && late->fused) late->pending = true;                                       // the caller waits for ev_dw_out itself, later
+    else if (late && late->pending) FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_prev, 0));   // ... likewise, after the first optimizer phase
     else FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
   }
   if (m->tw[0].present && d_out_img) FC_TRY(tower_reparam_grads(c, 0, grads));
@@ -1016,6 +1051,37 @@ extern "C" int fc_ce_loss_fwd_bwd(const float* logits, const int64_t* y, int32_t
   return fc_ce_fwd_bwd(logits, y, B, C, lossbuf, dlogits, (hipStream_t)stream);
 }
 
+// AdamW of every trainable segment the fused weight-gradient epilogue did NOT step (flag 0 in `fused`), as one chunked launch.  The
+// chunk table depends only on the model and on which problems took the grouped path, so it is built once and kept in the handle.
+static int adamw_rest(const fc_model* m, const std::vector<char>& fused, const FcAdamW& o, hipStream_t s) {
+  if (m->fused_host != fused || !m->rest_dev) {
+    std::vector<FcProxChunk> ch;
+    int64_t beg = -1, end = -1;
+    auto cut = [&]() {
+      for (int64_t q = beg; q >= 0 && q < end; q += FC_PROX_CHUNK) ch.push_back(FcProxChunk{q, (int32_t)std::min<int64_t>(FC_PROX_CHUNK, end - q), 0});
+      beg = end = -1;
+    };
+    for (size_t k = 0; k < m->segs.size(); ++k) {
+      const fc_segment& sg = m->segs[k];
+      const bool take = sg.trainable && sg.numel > 0 && !(k < fused.size() && fused[k]);
+      if (!take) continue;
+      if (beg >= 0 && sg.offset != end) cut();
+      if (beg < 0) beg = sg.offset;
+      end = sg.offset + sg.numel;
+    }
+    cut();
+    FC_CHECK_HIP(hipDeviceSynchronize());          // a previous step may still be reading the old table (once per handle in practice)
+    if (m->rest_dev) FC_CHECK_HIP(hipFree(m->rest_dev));
+    m->rest_dev = nullptr;
+    m->rest_chunks = (int)ch.size();
+    if (!ch.empty()) {
+      FC_CHECK_HIP(hipMalloc(&m->rest_dev, ch.size() * sizeof(FcProxChunk)));
+      FC_CHECK_HIP(hipMemcpy(m->rest_dev, ch.data(), ch.size() * sizeof(FcProxChunk), hipMemcpyHostToDevice));
+    }
+    m->fused_host = fused;
+  }
+  return fc_adamw_chunks((const FcProxChunk*)m->rest_dev, m->rest_chunks, o, s);
+}
 static int adamw_ranges(const fc_model* m, float* p, float* g, float* mm, float* vv, float lr, float b1, float b2, float eps, float wd, int step,
                         hipStream_t s, bf16_t* shadow = nullptr, const std::vector<char>* late_seg = nullptr, int want_late = 0) {
   // contiguous runs of trainable segments (padding included) -> one launch each; frozen segments are skipped like torch.
@@ -1208,21 +1274,32 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
   for (const fc_segment& sg : m->segs)
     if (strstr(sg.name, "aux_weight")) aux_any = true;
   static const bool late_opt = !(getenv("FC_LATE_OPT") && atoi(getenv("FC_LATE_OPT")) == 0);
+  static const bool fused_opt = !(getenv("FC_FUSED_OPT") && atoi(getenv("FC_FUSED_OPT")) == 0);
+  // compute weights for the next step: without re-param linears and with every segment trainable the bf16 shadow is written
+  // by the optimizer itself (one pass over the parameters instead of two)
+  bool all_trainable = true;
+  for (const fc_segment& sg : m->segs)
+    if (!sg.trainable) all_trainable = false;
+  const bool fuse_shadow = m->need_wc && m->dt == FC_BF16 && !aux_any && all_trainable;
+  // ... and in that case the AdamW step of every linear's weight and bias is taken by the weight-gradient launches themselves, chunk by
+  // chunk under the backward; what they do not cover (LayerNorm, embeddings, heads: 7 % of the parameters) is one small launch.
+  // (FedProx adds its term to the finished gradients, so it keeps the separate optimizer.)
+  const bool fused = fused_opt && fuse_shadow && !global_params;
   LateDw late;
+  FcAdamW fo = fc_adamw_consts(lr, beta1, beta2, eps, weight_decay, step);
+  fo.g0 = grads; fo.p = params; fo.m = exp_avg; fo.v = exp_avg_sq; fo.shadow = (bf16_t*)wc;
+  std::vector<char> fseg;
+  late.fused = fused;
   FC_PHASE(2);
-  FC_TRY(backward_impl(m, params, wc, d0, d1, grads, w, s, (late_opt && !aux_any && !global_params) ? &late : nullptr));
+  FC_TRY(backward_impl(m, params, wc, d0, d1, grads, w, s, (fused || (late_opt && !aux_any && !global_params)) ? &late : nullptr,
+                       fused ? &fo : nullptr, &fseg));
   FC_PHASE(3);
   if (global_params)   // FedproxClient.update: loss += mu * 0.5 * sum ||p - p_global||, before the optimizer step (fedproxclient.py:64-72)
     FC_TRY(fc_prox_term(m, params, global_params, mu, B, grads, lossbuf, prox_scratch, prox_scratch_bytes, stream));
-  // compute weights for the next step: without re-param linears and with every segment trainable the bf16 shadow is written
-  // by the AdamW kernel itself (one pass over the parameters instead of two)
-  bool has_aux = false, all_trainable = true;
-  for (const fc_segment& sg : m->segs) {
-    if (strstr(sg.name, "aux_weight")) has_aux = true;
-    if (!sg.trainable) all_trainable = false;
-  }
-  const bool fuse_shadow = m->need_wc && m->dt == FC_BF16 && !has_aux && all_trainable;
-  if (late.pending) {   // everything that does not wait for the last weight-gradient chunk, then the chunk, then the rest
+  if (fused) {
+    FC_TRY(adamw_rest(m, fseg, fo, s));
+    if (late.pending) FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
+  } else if (late.pending) {   // everything that does not wait for the last weight-gradient chunk, then the chunk, then the rest
     FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s, fuse_shadow ? (bf16_t*)wc : nullptr,
                         &late.late_seg, 0));
     FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
@@ -1370,6 +1447,26 @@ extern "C" int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, con
                             (hipStream_t)stream);
   }
   return fc_attn_bwd_generic(dt, qkv, o, dout, lse, delta, dqkv, B, N, H, d, scale, (hipStream_t)stream);
+}
+// one weight-gradient problem through the grouped kernels (wide = 1: 128x384 tiles, needs in % 384 == 0): tests / tools
+extern "C" int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, float* db, int32_t rows, int32_t out, int32_t in, void* stream) {
+  FcTnProblem p{(const bf16_t*)dY, (const bf16_t*)X, dW, db, out, in, in, out, in, rows, 0, 0};   // lda, ldb, ldc, M, N, K
+  FC_REQUIRE(fc_gemm_tn_grouped_supported(p), "fc_k_dw: operands must be 16-B aligned with out, in multiples of 8");
+  int tiles;
+  if (wide) {
+    FC_REQUIRE(fc_gemm_dw_wide_supported(p), "fc_k_dw: the wide kernel needs in %% 384 == 0");
+    tiles = fc_gemm_dw_wide_tiles(p, &p.tiles_n);
+  } else {
+    p.tiles_n = fc_cdiv(in, 128);
+    tiles = fc_cdiv(out, 128) * p.tiles_n;
+  }
+  FcTnProblem* dev = nullptr;
+  FC_CHECK_HIP(hipMalloc(&dev, sizeof(p)));
+  FC_CHECK_HIP(hipMemcpy(dev, &p, sizeof(p), hipMemcpyHostToDevice));
+  int r = wide ? fc_gemm_dw_wide(dev, 1, tiles, (hipStream_t)stream) : fc_gemm_tn_grouped(dev, 1, tiles, (hipStream_t)stream);
+  FC_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  FC_CHECK_HIP(hipFree(dev));
+  return r;
 }
 extern "C" int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd, int32_t step,
                           void* stream) {

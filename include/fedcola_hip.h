@@ -250,6 +250,10 @@ int fc_k_attention_fwd(int32_t impl, int32_t dt, const void* qkv, void* o, float
                        int32_t d, float scale, void* stream);
 int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, const void* o, const void* dout, const float* lse,
                        float* delta, void* dqkv, int32_t B, int32_t N, int32_t H, int32_t d, float scale, void* stream);
+/* one weight-gradient problem of the backward through the grouped kernels: dW[out,in] (fp32) = dY[rows,out]^T . X[rows,in] (bf16
+ * operands), db[out] = column sums of dY (may be NULL).  wide: 0 = 128x128 tiles, 1 = 128x384 tiles (needs in % 384 == 0).
+ * Test entry point: allocates its one-entry problem table and synchronises the stream. */
+int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, float* db, int32_t rows, int32_t out, int32_t in, void* stream);
 int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
                int32_t step, void* stream);
 int fc_k_cast(int32_t dt_out, const float* src, void* dst, int64_t n, void* stream);

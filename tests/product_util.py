@@ -15,7 +15,7 @@ def build_product(case_mk, precision="fp32", weights=None):
     return m.cuda()
 
 
-def product_step(model, kind, img, ids, y, lr, droppath=None, wd=0.0, step=1, state=None):
+def product_step(model, kind, img, ids, y, lr, droppath=None, wd=0.0, step=1, state=None, prepare=True):
     """One fc_client_step; returns (loss, grads_by_key, state)."""
     from fedcola_amd import _lib
     dev = model.flat.device
@@ -25,7 +25,8 @@ def product_step(model, kind, img, ids, y, lr, droppath=None, wd=0.0, step=1, st
                      loss=torch.zeros(2, device=dev))
     B = (img if kind != "txt" else ids).shape[0]
     n_txt = ids.shape[1] if kind != "img" else 0
-    model.prepare_weights(force=True)
+    if prepare:           # False: keep the bf16 compute weights the previous step's optimizer wrote
+        model.prepare_weights(force=True)
     ws = model.workspace(B, n_txt)
     imgd = img.cuda().contiguous() if kind != "txt" else None
     idsd = ids.cuda().contiguous() if kind != "img" else None

@@ -113,6 +113,25 @@ def test_gemm(impl, kind, prec, M, N, K):
         assert err <= t * max(1.0, scale), (err, scale, out_dt)
 
 
+@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("rows,out,inn", [(197 * 4, 384, 384), (1000, 1152, 384), (64 * 5 + 17, 1536, 384), (2048, 384, 1536), (777, 200, 768),
+                                          (12608, 384, 384)])
+def test_grouped_weight_gradient_kernels(wide, rows, out, inn):
+    """dW = dY^T . X (fp32 out) and db = colsum(dY) through the 128x128 and the 128x384 grouped kernels: ragged row counts (k tail inside
+    the last 64-row tile), out not a multiple of 128, two column tiles (in = 768 / 1536), the model's full reduction length."""
+    g = torch.Generator().manual_seed(rows + out + inn)
+    dY = (torch.randn(rows, out, generator=g) * 0.5).bfloat16()
+    X = (torch.randn(rows, inn, generator=g) * 0.5).bfloat16()
+    dW = torch.full((out, inn), float("nan"), device="cuda")
+    db = torch.full((out,), float("nan"), device="cuda")
+    L().check(L().lib().fc_k_dw(wide, P(dev(dY)), P(dev(X)), P(dW), P(db), rows, out, inn, S()))
+    ref = dY.double().t() @ X.double()
+    tol = 2e-5 * math.sqrt(rows) + 1e-6
+    assert (dW.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    refb = dY.double().sum(0)
+    assert (db.double().cpu() - refb).abs().max().item() <= tol * max(1.0, refb.abs().max().item())
+
+
 def attn_ref(qkv, B, N, H, d):
     q5 = qkv.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4).double()
     q, k, v = q5[0] * d ** -0.5, q5[1], q5[2]

@@ -138,3 +138,36 @@ def test_microbatch_chains_do_not_change_the_result(tmp_path):
     for k in out["1"]:
         scale = max(float(out["1"][k].abs().max()), 1e-9)
         assert float((out["1"][k] - out["2"][k]).abs().max()) <= 2e-5 * scale, k
+
+
+@pytest.mark.parametrize("kind", ["img+txt", "img"])
+def test_fused_optimizer_is_bit_identical_to_the_separate_one(tmp_path, kind):
+    """fc_client_step takes the AdamW step of the linears inside the weight-gradient GEMM's epilogue (FC_FUSED_OPT, read once per
+    process, default on).  One step with weight decay from non-trivial moments: the linears' parameters, both moments, bf16 compute
+    weights and gradients are the same BITS as with the separate optimizer pass."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for fused in ("0", "1"):
+        f = str(tmp_path / f"f{fused}.pt")
+        env = dict(os.environ, FC_FUSED_OPT=fused)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "opt_check.py"), kind, f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[fused] = torch.load(f)
+    assert abs(out["0"]["loss"] - out["1"]["loss"]) <= 1e-5          # the loss sum is atomic: equal up to its order
+    n_lin = 0
+    for name, (o, c) in out["0"]["segs"].items():
+        linear = ".attn." in name or ".mlp." in name
+        for k in ("g", "p", "m", "v"):
+            a, b = out["0"][k][o:o + c], out["1"][k][o:o + c]
+            if linear:      # stepped inside the weight-gradient epilogue
+                assert torch.equal(a, b), f"{k} of {name}: {int((a != b).sum())} of {c} elements differ"
+            else:           # embedding / LayerNorm gradients are summed with atomics: equal up to the order of the sum
+                assert float((a - b).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-12), f"{k} of {name}"
+        if linear:
+            n_lin += c
+            wa, wb = out["0"]["wc"][o:o + c], out["1"]["wc"][o:o + c]
+            assert torch.equal(wa, wb), f"bf16 compute weights of {name}"
+    assert n_lin > 0.8 * out["0"]["p"].numel()

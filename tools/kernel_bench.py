@@ -36,3 +36,10 @@ run("ln fwd", lambda: _lib.check(L.fc_k_layernorm_fwd(1, P(x), P(g), P(b_), P(y)
 run("ln bwd", lambda: _lib.check(L.fc_k_layernorm_bwd(1, P(dy), P(x), P(mean), P(rstd), P(g), P(res), P(dx), P(dg), P(db), M, D, sp)))
 part = torch.empty(int(L.fc_k_layernorm_partial_floats(M, D)), device="cuda")
 run("ln bwd partial", lambda: _lib.check(L.fc_k_layernorm_bwd_partial(1, P(dy), P(x), P(mean), P(rstd), P(g), P(res), P(dx), P(dg), P(db), M, D, P(part), sp)))
+# the four weight-gradient problems of one layer through both grouped kernels (one problem per launch; in the step a chunk of 4
+# layers x 2 towers is ONE launch, so these are per-problem device times, not the in-step cost)
+for name, out, inn in (("dW qkv", 1152, 384), ("dW proj", 384, 384), ("dW fc1", 1536, 384), ("dW fc2", 384, 1536)):
+    dYm, Xm = bf(M, out), bf(M, inn)
+    dWm, dbm = torch.empty(out, inn, device="cuda"), torch.empty(out, device="cuda")
+    for wide in (0, 1):
+        run(f"{name} wide={wide}", lambda: _lib.check(L.fc_k_dw(wide, P(dYm), P(Xm), P(dWm), P(dbm), M, out, inn, sp)))

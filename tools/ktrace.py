@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Per-launch-group kernel durations from a rocprofv3 --kernel-trace csv directory: consecutive dispatches of one kernel
 (same name and grid) form a group (a micro-benchmark loop); prints the median / mean / min duration of each group.
-usage: tools/ktrace.py <dir> [min_group]"""
-import csv, glob, statistics, sys
+usage: tools/ktrace.py <dir> [min_group]      (KTRACE_BYNAME=1: one group per (kernel, grid) regardless of adjacency -- for loops whose
+launches are separated by copy kernels)"""
+import csv, glob, os, statistics, sys
 d = sys.argv[1]; min_group = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
 rows = list(csv.DictReader(open(f[0])))
@@ -11,7 +12,14 @@ groups = []
 for r in rows:
     key = (r['Kernel_Name'], r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', ''))
     dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    if groups and groups[-1][0] == key:
+    if os.environ.get("KTRACE_BYNAME"):
+        for g in groups:
+            if g[0] == key:
+                g[1].append(dur)
+                break
+        else:
+            groups.append((key, [dur]))
+    elif groups and groups[-1][0] == key:
         groups[-1][1].append(dur)
     else:
         groups.append((key, [dur]))
