@@ -99,6 +99,13 @@ __global__ void __launch_bounds__(256) k_ln_fwd_v(const T* __restrict__ x, const
 // dependent ones (measured at M = 12 608, D = 384: 27 us -> see profiles/r02).  dgamma / dbeta: per-lane column sums over the
 // wave's rows, combined across the 4 waves in LDS, one partial row per block (or atomics without `partial`).
 #define LNB_R 4
+#ifdef FC_PROBES
+__device__ long long g_ln_stamps[1024 * 8];     // tools build: s_memrealtime stamps of wave 0 of each block (10 ns units)
+#define LN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ln_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int fc_dbg_ln_read_stamps(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ln_stamps), sizeof(long long) * 1024 * 8); }
+#else
+#define LN_STAMP(i) do {} while (0)
+#endif
 template <typename T, int CH>      // CH: 8-column chunks per lane (1: D <= 512)
 __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ g, const T* res, T* dx,
@@ -108,6 +115,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
 #define RED(a, w, i) red_dyn[((a) * 4 + (w)) * D + (i)]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nc = D >> 3;
+  LN_STAMP(0);
   float ag[CH][8], ab[CH][8], gg[CH][8];
 #pragma unroll
   for (int t = 0; t < CH; ++t) {
@@ -136,6 +144,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
         }
       }
     }
+    LN_STAMP(1);
 #pragma unroll
     for (int q = 0; q < LNB_R; ++q) {
       s1[q] = 0.f; s2[q] = 0.f;
@@ -153,11 +162,13 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
         }
       }
     }
+    LN_STAMP(2);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {                      // the eight reductions side by side
 #pragma unroll
       for (int q = 0; q < LNB_R; ++q) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
     }
+    LN_STAMP(3);
 #pragma unroll
     for (int q = 0; q < LNB_R; ++q) {
       if (row[q] >= M) continue;
@@ -181,6 +192,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
       }
     }
   }
+  LN_STAMP(4);
 #pragma unroll
   for (int t = 0; t < CH; ++t) {
     int c = lane + 64 * t;
@@ -190,12 +202,14 @@ __global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, cons
     }
   }
   __syncthreads();
+  LN_STAMP(5);
   if (partial) {  // [block][dg(D) | db(D)], reduced later by k_ln_reduce_grouped (no same-address atomic storm)
     float* pp = partial + (size_t)blockIdx.x * 2 * D;
     for (int i = threadIdx.x; i < D; i += 256) {
       pp[i] = RED(0, 0, i) + RED(0, 1, i) + RED(0, 2, i) + RED(0, 3, i);
       pp[D + i] = RED(1, 0, i) + RED(1, 1, i) + RED(1, 2, i) + RED(1, 3, i);
     }
+    LN_STAMP(6);
     return;
   }
   for (int i = threadIdx.x; i < D; i += 256) {

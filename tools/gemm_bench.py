@@ -13,6 +13,7 @@ shapes = [("NT fc1", 0, 12608, 1536, 384), ("NT qkv", 0, 12608, 1152, 384), ("NT
 if os.environ.get("GEMM_SHAPES"):   # "kind,M,N,K;kind,M,N,K"
     shapes = [("custom", *map(int, t.split(","))) for t in os.environ["GEMM_SHAPES"].split(";")]
     only = None
+custom = bool(os.environ.get("GEMM_SHAPES"))   # custom shapes run without a bias: the PLAIN epilogue, as bench.py's roofline kernel
 sp = _lib.stream_ptr()
 for name, kind, M, N, K in shapes:
     if only and only not in name: continue
@@ -22,11 +23,11 @@ for name, kind, M, N, K in shapes:
     out_dt = torch.float32 if kind == 2 else torch.bfloat16
     Cm = torch.empty(M, N, device="cuda", dtype=out_dt); bias = torch.randn(N, device="cuda")
     for _ in range(3):
-        _lib.check(L.fc_k_gemm(1, kind, 1, 0 if kind == 2 else 1, P(A), P(B), P(Cm), M, N, K, P(bias), 0, sp))
+        _lib.check(L.fc_k_gemm(1, kind, 1, 0 if kind == 2 else 1, P(A), P(B), P(Cm), M, N, K, None if custom else P(bias), 0, sp))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        _lib.check(L.fc_k_gemm(1, kind, 1, 0 if kind == 2 else 1, P(A), P(B), P(Cm), M, N, K, P(bias), 0, sp))
+        _lib.check(L.fc_k_gemm(1, kind, 1, 0 if kind == 2 else 1, P(A), P(B), P(Cm), M, N, K, None if custom else P(bias), 0, sp))
     e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     print(f"{name:12s} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s")
