@@ -22,7 +22,7 @@ class FcModelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "has_img", "has_txt", "img_size", "patch", "in_chans", "dim", "depth", "heads", "mlp_hidden", "vocab",
         "max_text_len", "task_img", "task_txt", "num_classes_img", "num_classes_txt", "with_aux", "aux_trained",
-        "aux_attn_only", "aux_mlp_only", "precision")]
+        "aux_attn_only", "aux_mlp_only", "precision", "colearn_attn")]
 
 
 class FcSegment(C.Structure):

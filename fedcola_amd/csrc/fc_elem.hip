@@ -776,6 +776,16 @@ __global__ void __launch_bounds__(256) k_adamw_chunks(const FcProxChunk* __restr
     }
   }
 }
+__global__ void __launch_bounds__(256) k_add_chunks(float* __restrict__ dst, const float* __restrict__ src, const FcProxChunk* __restrict__ chunks) {
+  const FcProxChunk c = chunks[blockIdx.x];
+  for (int i = threadIdx.x; i < c.n; i += 256) dst[c.offset + i] += src[c.offset + i];
+}
+int fc_add_chunks(float* dst, const float* src, const FcProxChunk* chunks_dev, int nchunks, hipStream_t s) {
+  if (nchunks <= 0) return 0;
+  hipLaunchKernelGGL(k_add_chunks, dim3(nchunks), dim3(256), 0, s, dst, src, chunks_dev);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
 int fc_adamw_chunks(const FcProxChunk* chunks_dev, int nchunks, const FcAdamW& o, hipStream_t s) {
   if (nchunks <= 0 || FC_ABLATED("adamw")) return 0;
   hipLaunchKernelGGL(k_adamw_chunks, dim3(nchunks), dim3(256), 0, s, chunks_dev, o);

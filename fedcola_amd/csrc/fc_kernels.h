@@ -85,6 +85,7 @@ __device__ __forceinline__ void fc_adamw_elem(float& p, float g, float& m, float
 // AdamW over a table of chunks (<= FC_PROX_CHUNK consecutive elements each; FcProxChunk.seg unused): everything the fused epilogue
 // does not cover, in one launch
 struct FcProxChunk;
+int fc_add_chunks(float* dst, const float* src, const FcProxChunk* chunks_dev, int nchunks, hipStream_t s);   // dst[c] += src[c] over the chunks
 int fc_adamw_chunks(const FcProxChunk* chunks_dev, int nchunks, const FcAdamW& o, hipStream_t s);
 int fc_cast(int dt_out, const float* src, void* dst, size_t n, hipStream_t s);
 // W_eff = W + s*A (K9) into dst (type dt)

@@ -27,6 +27,7 @@ struct LinearP {
   int64_t w = -1, b = -1, scale = -1, aux = -1;
   int out = 0, in = 0;
   int seg_w = -1;
+  bool shared = false;   // colearn_param == 'attn': this tower USES another tower's linear; its weight gradients go to the side buffer
 };
 struct BlockP {
   int64_t n1w, n1b, n2w, n2b;
@@ -73,6 +74,7 @@ struct fc_model {
   ~fc_model() {
     if (tables_dev) (void)hipFree(tables_dev);
     if (rest_dev) (void)hipFree(rest_dev);
+    if (shared_dev) (void)hipFree(shared_dev);
     if (ev_dw_in) (void)hipEventDestroy(ev_dw_in);
     for (int k = 0; k < 3; ++k) {
       if (ev_dw_in2[k]) (void)hipEventDestroy(ev_dw_in2[k]);
@@ -88,6 +90,11 @@ struct fc_model {
   int64_t total = 0;
   TowerP tw[2];
   int64_t normw = -1, normb = -1;
+  // colearn_param == 'attn': [shared_lo, shared_hi) = span of the flat buffer that holds the shared Attention linears (the second
+  // tower writes its dW / db into a workspace buffer of that span, added to the gradients once both towers are done)
+  int64_t shared_lo = 0, shared_hi = 0;
+  std::vector<FcProxChunk> shared_chunks;
+  mutable void* shared_dev = nullptr;
   int dt;  // FC_F32 / FC_BF16 activation + compute-weight type
   bool need_wc;
   int64_t add(const std::string& name, std::vector<int64_t> shape, int trainable = 1) {
@@ -166,8 +173,14 @@ extern "C" int fc_model_create(const fc_model_cfg* c, fc_model_t** out) {
       BlockP& b = t.blocks[l];
       b.n1w = m->add(p + ".norm1.weight", {D});
       b.n1b = m->add(p + ".norm1.bias", {D});
-      add_linear(m, b.qkv, p + ".attn.qkv", 3 * D, D, aux_attn, c->aux_trained);
-      add_linear(m, b.proj, p + ".attn.proj", D, D, aux_attn, c->aux_trained);
+      if (i == 1 && c->colearn_attn && m->tw[0].present) {   // mome.py:836-840: block.attn = self.blockses[main_idx][j].attn
+        b.qkv = m->tw[0].blocks[l].qkv;
+        b.proj = m->tw[0].blocks[l].proj;
+        b.qkv.shared = b.proj.shared = true;
+      } else {
+        add_linear(m, b.qkv, p + ".attn.qkv", 3 * D, D, aux_attn, c->aux_trained);
+        add_linear(m, b.proj, p + ".attn.proj", D, D, aux_attn, c->aux_trained);
+      }
       b.n2w = m->add(p + ".norm2.weight", {D});
       b.n2b = m->add(p + ".norm2.bias", {D});
       add_linear(m, b.fc1, p + ".mlp.fc1", c->mlp_hidden, D, aux_mlp, c->aux_trained);
@@ -176,6 +189,16 @@ extern "C" int fc_model_create(const fc_model_cfg* c, fc_model_t** out) {
   }
   m->normw = m->add("norm.weight", {D});
   m->normb = m->add("norm.bias", {D});
+  if (c->colearn_attn && c->has_img && c->has_txt) {
+    m->shared_lo = m->tw[0].blocks[0].qkv.w;
+    for (const BlockP& b : m->tw[0].blocks)
+      for (const LinearP* L : {&b.qkv, &b.proj})
+        for (int64_t off : {L->w, L->b}) {
+          const int64_t n = off == L->w ? (int64_t)L->out * L->in : L->out;
+          for (int64_t o = 0; o < n; o += FC_PROX_CHUNK) m->shared_chunks.push_back(FcProxChunk{off + o, (int32_t)std::min<int64_t>(FC_PROX_CHUNK, n - o), 0});
+          m->shared_hi = std::max<int64_t>(m->shared_hi, (off + n + 63) / 64 * 64);
+        }
+  }
   for (int i = 0; i < 2; ++i) {
     TowerP& t = m->tw[i];
     if (!t.present || t.task != FC_TASK_CLS || t.ncls <= 0) continue;
@@ -230,6 +253,7 @@ struct Ws {
   int dp_stride = 0, dp_off = 0;   // drop-path table: samples per row / first sample of this (micro-batch) view
   const float* droppath;
   const int64_t* ids;
+  float* shared_g = nullptr;       // colearn_param == 'attn': the second tower's gradients of the shared Attention linears
   size_t bytes;
 };
 struct Bump {
@@ -313,6 +337,7 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
   w.max_ln = 12 * c.depth;
   w.lntab = (FcLnReduce*)bp.take(sizeof(FcLnReduce) * w.max_ln);
   w.loss_scratch = (float*)bp.take(sizeof(float) * (2 * (size_t)B * B + 2 * B + 64));
+  w.shared_g = m->shared_hi > m->shared_lo ? (float*)bp.take(sizeof(float) * (size_t)(m->shared_hi - m->shared_lo)) : nullptr;
   w.bytes = bp.off;
   w.B = B; w.n_txt = n_txt;
   w.dp_stride = B; w.dp_off = 0;
@@ -422,6 +447,7 @@ struct Ctx {
   bool no_wgrad = false;                       // micro-batch slice: the full-batch weight gradients are queued by the driver
   int n_more = 0;                              // flush_dw also orders the chunk after the other micro-batch chains' streams
   std::vector<FcLnReduce>* lnq = nullptr;      // non-null: LayerNorm dgamma/dbeta partials are queued likewise
+  float* gshared = nullptr;                    // colearn 'attn': base such that gshared + L.w is the side buffer's slot of a shared linear
   const FcAdamW* fopt = nullptr;               // non-null: the grouped weight-gradient launches also take the AdamW step of what they produce
   std::vector<char>* fused_seg = nullptr;      // ... and the segments they cover are flagged here
   int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res, void* dx, float* dg,
@@ -809,7 +835,8 @@ static int weight_grad(const Ctx& c, const void* dY, const void* X, int M, int o
   return 0;
 }
 static int linear_bwd_params(const Ctx& c, const LinearP& L, const void* dY, const void* X, int M, float* grads) {
-  return weight_grad(c, dY, X, M, L.out, L.in, grads + L.w, grads + L.b);
+  float* g = L.shared ? c.gshared : grads;     // a tower that borrows the linear accumulates beside the owner, summed afterwards
+  return weight_grad(c, dY, X, M, L.out, L.in, g + L.w, g + L.b);
 }
 
 enum { PH_ALL = -1, PH_HEAD = 0, PH_LAYER = 1, PH_EMBED = 2, PH_WGRAD_LAYER = 3, PH_WGRAD_EMBED = 4 };
@@ -946,6 +973,12 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     }
   }
   c.lnq = &lnq;
+  const bool shared_attn = w.shared_g != nullptr;
+  if (shared_attn) {      // the fallback weight-gradient paths accumulate (split-K atomics, colsum): start from zero like `grads`
+    FC_CHECK_HIP(hipMemsetAsync(w.shared_g, 0, sizeof(float) * (size_t)(m->shared_hi - m->shared_lo), s));
+    c.gshared = w.shared_g - m->shared_lo;
+    late = nullptr;       // every weight gradient is complete before the sum below
+  }
   const bool run0 = m->tw[0].present && d_out_img, run1 = m->tw[1].present && d_out_txt;
   if (run0 && run1) {
     FC_TRY(fork_side(m, s));
@@ -1026,6 +1059,13 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     if (late && late->fused) late->pending = true;                                       // the caller waits for ev_dw_out itself, later
     else if (late && late->pending) FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_prev, 0));   // ... likewise, after the first optimizer phase
     else FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
+  }
+  if (shared_attn) {      // both towers' contributions exist now (dW stream joined above): owner += borrower
+    if (!m->shared_dev) {
+      FC_CHECK_HIP(hipMalloc(&m->shared_dev, m->shared_chunks.size() * sizeof(FcProxChunk)));
+      FC_CHECK_HIP(hipMemcpy(m->shared_dev, m->shared_chunks.data(), m->shared_chunks.size() * sizeof(FcProxChunk), hipMemcpyHostToDevice));
+    }
+    FC_TRY(fc_add_chunks(grads, c.gshared, (const FcProxChunk*)m->shared_dev, (int)m->shared_chunks.size(), s));
   }
   if (m->tw[0].present && d_out_img) FC_TRY(tower_reparam_grads(c, 0, grads));
   if (m->tw[1].present && d_out_txt) FC_TRY(tower_reparam_grads(c, 1, grads));
@@ -1284,7 +1324,7 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
   // ... and in that case the AdamW step of every linear's weight and bias is taken by the weight-gradient launches themselves, chunk by
   // chunk under the backward; what they do not cover (LayerNorm, embeddings, heads: 7 % of the parameters) is one small launch.
   // (FedProx adds its term to the finished gradients, so it keeps the separate optimizer.)
-  const bool fused = fused_opt && fuse_shadow && !global_params;
+  const bool fused = fused_opt && fuse_shadow && !global_params && !m->cfg.colearn_attn;
   LateDw late;
   FcAdamW fo = fc_adamw_consts(lr, beta1, beta2, eps, weight_decay, step);
   fo.g0 = grads; fo.p = params; fo.m = exp_avg; fo.v = exp_avg_sq; fo.shadow = (bf16_t*)wc;

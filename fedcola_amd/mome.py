@@ -110,7 +110,8 @@ class ModalityAgnosticTransformer(nn.Module):
             vocab=vocab_size, max_text_len=max_text_len, task_img=_TASKS[tasks[0]], task_txt=_TASKS[tasks[1]],
             num_classes_img=int(num_classes[0] or 0), num_classes_txt=int(num_classes[1] or 0), with_aux=int(self.with_aux),
             aux_trained=int(self.aux_trained), aux_attn_only=int(self.aux_attn_only), aux_mlp_only=int(self.aux_mlp_only),
-            precision=_lib.FC_PREC_BF16 if precision == "bf16" else _lib.FC_PREC_FP32)
+            precision=_lib.FC_PREC_BF16 if precision == "bf16" else _lib.FC_PREC_FP32,
+            colearn_attn=int(colearn_param == "attn" and modalities[0] == "img" and modalities[1] == "txt"))
         self._handle = _Handle(cfg)
         self.flat = nn.Parameter(torch.zeros(self._handle.total, dtype=torch.float32))
         self._wc = None
@@ -120,6 +121,7 @@ class ModalityAgnosticTransformer(nn.Module):
         self._alias: Dict[str, str] = {}
         if init:
             self._reference_init()
+        self.sync_shared_weights()                 # mome.py:815: the constructor ends with it
 
     # ------------------------------------------------------------------ parameter views
     @property
@@ -155,7 +157,9 @@ class ModalityAgnosticTransformer(nn.Module):
                 self._view(p + ".norm1.weight").fill_(1.0)
                 self._view(p + ".norm2.weight").fill_(1.0)
                 for nm, (o, n) in (("attn.qkv", (3 * D, D)), ("attn.proj", (D, D)), ("mlp.fc1", (Hd, D)), ("mlp.fc2", (D, Hd))):
-                    lin = nn.Linear(n, o)
+                    lin = nn.Linear(n, o)                                   # always drawn: the reference builds every tower first
+                    if f"{p}.{nm}.weight" not in self.segments:             # colearn 'attn': this module is dropped for the main tower's
+                        continue
                     self._view(f"{p}.{nm}.weight").copy_(lin.weight)
                     self._view(f"{p}.{nm}.bias").copy_(lin.bias)
                     if f"{p}.{nm}.aux_weight" in self.segments:           # build_aux: aux_weight is the old layer's weight
@@ -178,18 +182,20 @@ class ModalityAgnosticTransformer(nn.Module):
           tower's tensors.  Here: alias keys that are views of the same flat segments (``_alias``).
         * colearn_param == 'blocks': the reference's loop only rebinds its loop variable (``blocks = self.blockses[main_idx]``,
           :832-835) -- no module changes hands.  Reproduced as the no-op it is.
-        * colearn_param == 'attn': the text tower's attention modules ARE replaced by the image tower's (:836-840): shared qkv / proj
-          parameters with gradients from both towers.  Not implemented (no reference script uses it): raises."""
+        * colearn_param == 'attn': the other tower's Attention modules ARE replaced by the main tower's (:836-840): shared qkv / proj
+          parameters, gradients from both towers.  The C layout gives the second tower no attention segments (fc_model_cfg.colearn_attn);
+          here the second tower's keys alias the main tower's, as in the reference's state_dict."""
         main_idx = next(i for i, m in enumerate(self.modalities) if m is not None)
         self._alias = {}
         if self.scope == "all":
             for i, m in enumerate(self.modalities):
                 if m is None:
                     self._alias[f"blockses.{i}."] = f"blockses.{main_idx}."
-        if self.colearn_param in ("none", "blocks"):
-            return
-        if self.colearn_param == "attn" and sum(m is not None for m in self.modalities) > 1:
-            raise NotImplementedError("colearn_param='attn' (attention modules shared between the towers, mome.py:836-840) is not implemented")
+        if self.colearn_param == "attn":
+            for i, m in enumerate(self.modalities):
+                if m is not None and i != main_idx:
+                    for l in range(self.depth):
+                        self._alias[f"blockses.{i}.{l}.attn."] = f"blockses.{main_idx}.{l}.attn."
 
     def _alias_keys(self):
         """(alias key, target key) pairs created by sync_shared_weights (scope == 'all'), in the target's order."""
@@ -247,12 +253,28 @@ class ModalityAgnosticTransformer(nn.Module):
         for _, p in self.named_parameters():
             yield p
 
+    _SLOTS = ("norm1.", "attn.qkv.", "attn.proj.", "norm2.", "mlp.fc1.", "mlp.fc2.")
+
+    @classmethod
+    def _canon(cls, k):
+        """Sort key that puts alias keys where the reference's module traversal lists them (embeddings, blockses.{i}.{l} in
+        norm1 / attn.qkv / attn.proj / norm2 / mlp.fc1 / mlp.fc2 order, norm, heads)."""
+        parts = k.split(".")
+        if parts[0] == "embeddings":
+            return (0, int(parts[1]), 0, 0)
+        if parts[0] == "blockses":
+            rest = ".".join(parts[3:])
+            slot = next((n for n, sl in enumerate(cls._SLOTS) if rest.startswith(sl)), len(cls._SLOTS))
+            return (1, int(parts[1]), int(parts[2]), slot)
+        return (2 if parts[0] == "norm" else 3, 0, 0, 0)
+
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         sd = OrderedDict() if destination is None else destination
-        for k in self.segments:
-            sd[prefix + k] = self._view(k)
-        for ak, tk in self._alias_keys():                  # scope == 'all': the absent tower's slot aliases the main tower
-            sd[prefix + ak] = self._view(tk)
+        items = [(k, k) for k in self.segments] + list(self._alias_keys())   # alias keys: views of the owner's segment
+        if self._alias:
+            items.sort(key=lambda kv: self._canon(kv[0]))                    # stable: keys of one slot keep their order
+        for k, tk in items:
+            sd[prefix + k] = self._view(tk)
         return sd
 
     @torch.no_grad()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 2   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial */
+#define FC_ABI_VERSION 3   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw */
 
 enum { FC_PREC_FP32 = 0, FC_PREC_BF16 = 1 };
 enum { FC_TASK_NONE = 0, FC_TASK_CLS = 1, FC_TASK_RTV = 2 };
@@ -38,6 +38,9 @@ typedef struct fc_model_cfg {
   int32_t num_classes_img, num_classes_txt;
   int32_t with_aux, aux_trained, aux_attn_only, aux_mlp_only; /* CrossModalReparamLinear, mome.py:42-97,771-786 */
   int32_t precision;                    /* FC_PREC_*: storage type of activations / compute weights */
+  int32_t colearn_attn;                 /* colearn_param == 'attn' (mome.py:836-840): with both towers present the text tower's
+                                         * Attention modules ARE the image tower's -- no segments of their own, gradients of both
+                                         * towers summed into the image tower's qkv / proj segments.  ABI 3. */
 } fc_model_cfg;
 
 typedef struct fc_model fc_model_t;

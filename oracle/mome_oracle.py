@@ -59,6 +59,7 @@ class OracleCfg:
     aux_trained: bool = False
     aux_attn_only: bool = False
     aux_mlp_only: bool = False
+    colearn_attn: bool = False      # colearn_param == 'attn' (mome.py:836-840): every other tower's Attention module IS the main tower's
 
     @property
     def n_patches(self) -> int:
@@ -159,16 +160,18 @@ def _lin_weight(p: Dict[str, Tensor], prefix: str):
     return W
 
 
-def block_fwd(p, pre: str, x: Tensor, heads: int, dp1: Optional[Tensor], dp2: Optional[Tensor]):
+def block_fwd(p, pre: str, x: Tensor, heads: int, dp1: Optional[Tensor], dp2: Optional[Tensor], apre: Optional[str] = None):
     """Block.forward mome.py:225-228.  dp1/dp2: per-sample drop-path multipliers [B] (already /keep).
-    R(): bf16 storage points of the throughput mode (identity unless emulate_bf16())."""
+    R(): bf16 storage points of the throughput mode (identity unless emulate_bf16()).
+    apre: block whose Attention module this block uses (colearn_param == 'attn': the main tower's), default its own."""
+    apre = apre or pre
     B, N, D = x.shape
     d = D // heads
     scale = d ** -0.5
     h1, s1 = ln_fwd(x, p[pre + ".norm1.weight"], p[pre + ".norm1.bias"], LN_EPS_BLOCK)
     h1 = R(h1)
-    Wqkv = R(_lin_weight(p, pre + ".attn.qkv"))
-    qkv = R(linear_fwd(h1, Wqkv, p[pre + ".attn.qkv.bias"]))
+    Wqkv = R(_lin_weight(p, apre + ".attn.qkv"))
+    qkv = R(linear_fwd(h1, Wqkv, p[apre + ".attn.qkv.bias"]))
     qkv5 = qkv.reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)          # mome.py:153
     q, k, v = qkv5[0] * scale, qkv5[1], qkv5[2]                            # mome.py:156
     S = q @ k.transpose(-2, -1)                                           # mome.py:157 (fp32)
@@ -182,8 +185,8 @@ def block_fwd(p, pre: str, x: Tensor, heads: int, dp1: Optional[Tensor], dp2: Op
         P = torch.softmax(S, dim=-1)                                      # mome.py:162
         O4 = P @ v
     O = R(O4.transpose(1, 2).reshape(B, N, D))                            # mome.py:165
-    Wproj = R(_lin_weight(p, pre + ".attn.proj"))
-    a = linear_fwd(O, Wproj, p[pre + ".attn.proj.bias"])
+    Wproj = R(_lin_weight(p, apre + ".attn.proj"))
+    a = linear_fwd(O, Wproj, p[apre + ".attn.proj.bias"])
     if dp1 is not None:
         a = a * dp1.view(B, 1, 1)
     x1 = R(x + a)
@@ -219,7 +222,8 @@ def _acc(grads, k, g):
     grads[k] = g if k not in grads else grads[k] + g
 
 
-def block_bwd(p, pre: str, dx2: Tensor, c, heads: int, grads, aux_trained: bool):
+def block_bwd(p, pre: str, dx2: Tensor, c, heads: int, grads, aux_trained: bool, apre: Optional[str] = None):
+    apre = apre or pre            # shared Attention module: its gradients accumulate under the owner's keys
     B, N, D = dx2.shape
     d = D // heads
     scale = d ** -0.5
@@ -239,7 +243,7 @@ def block_bwd(p, pre: str, dx2: Tensor, c, heads: int, grads, aux_trained: bool)
     da = dx1 if c["dp1"] is None else R(dx1 * c["dp1"].view(B, 1, 1))
     dO, dWp, dbp = linear_bwd(da, c["O"], c["Wproj"])
     dO = R(dO)
-    _lin_grads(grads, p, pre + ".attn.proj", dWp, dbp, aux_trained)
+    _lin_grads(grads, p, apre + ".attn.proj", dWp, dbp, aux_trained)
     dO4 = dO.reshape(B, N, heads, d).transpose(1, 2)                      # [B,H,N,d]
     P, q, k, v = c["P"], c["q"], c["k"], c["v"]
     dP = dO4 @ v.transpose(-2, -1)
@@ -256,11 +260,34 @@ def block_bwd(p, pre: str, dx2: Tensor, c, heads: int, grads, aux_trained: bool)
     dqkv = R(torch.stack([dq, dk, dV], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * D))
     dh1, dWq, dbq = linear_bwd(dqkv, c["h1"], c["Wqkv"])
     dh1 = R(dh1)
-    _lin_grads(grads, p, pre + ".attn.qkv", dWq, dbq, aux_trained)
+    _lin_grads(grads, p, apre + ".attn.qkv", dWq, dbq, aux_trained)
     dxn, dg1, dbb1 = ln_bwd(dh1, p[pre + ".norm1.weight"], c["s1"])
     _acc(grads, pre + ".norm1.weight", dg1)
     _acc(grads, pre + ".norm1.bias", dbb1)
     return R(dx1 + dxn)
+
+
+def _attn_owner(cfg: OracleCfg, i: int, l: int) -> Optional[str]:
+    if not cfg.colearn_attn:
+        return None
+    main = next(j for j, m in enumerate(cfg.modalities) if m is not None)     # mome.py:819-822
+    return f"blockses.{main}.{l}"
+
+
+def resolve_colearn(p: Dict[str, Tensor], cfg: OracleCfg) -> Dict[str, Tensor]:
+    """state_dict-keyed weights -> named_parameters-keyed weights of a colearn_param == 'attn' model.  The reference's state_dict
+    lists the shared Attention tensors under BOTH towers' keys; load_state_dict copies key by key, so the value under the LATER
+    key (the other tower's) is what the shared tensor holds afterwards.  named_parameters() de-duplicates to the owner's key."""
+    if not cfg.colearn_attn:
+        return p
+    main = next(j for j, m in enumerate(cfg.modalities) if m is not None)
+    out = dict(p)
+    for k in list(p):
+        for i, m in enumerate(cfg.modalities):
+            pre = f"blockses.{i}."
+            if m is not None and i != main and k.startswith(pre) and ".attn." in k:
+                out[f"blockses.{main}." + k[len(pre):]] = out.pop(k)
+    return out
 
 
 def forward(p: Dict[str, Tensor], cfg: OracleCfg, x: Sequence[Optional[Tensor]], feat_out: bool = False,
@@ -302,7 +329,7 @@ def forward(p: Dict[str, Tensor], cfg: OracleCfg, x: Sequence[Optional[Tensor]],
         for l in range(cfg.depth):
             dp1 = dp_masks.get((i, l, 0)) if dp_masks else None
             dp2 = dp_masks.get((i, l, 1)) if dp_masks else None
-            h, bc = block_fwd(p, f"blockses.{i}.{l}", h, cfg.heads, dp1, dp2)
+            h, bc = block_fwd(p, f"blockses.{i}.{l}", h, cfg.heads, dp1, dp2, _attn_owner(cfg, i, l))
             tc["blocks"].append(bc)
         feats, tc["final_ln"] = ln_fwd(h, p["norm.weight"], p["norm.bias"], LN_EPS_FINAL)   # mome.py:906
         f = feats[:, 0]
@@ -342,7 +369,7 @@ def backward(p: Dict[str, Tensor], cfg: OracleCfg, cache, d_outs: Sequence[Optio
         _acc(grads, "norm.weight", dgn)                                   # shared by both towers
         _acc(grads, "norm.bias", dbn)
         for l in reversed(range(cfg.depth)):
-            dh = block_bwd(p, f"blockses.{i}.{l}", dh, tc["blocks"][l], cfg.heads, grads, cfg.aux_trained)
+            dh = block_bwd(p, f"blockses.{i}.{l}", dh, tc["blocks"][l], cfg.heads, grads, cfg.aux_trained, _attn_owner(cfg, i, l))
         if mod == "img":
             _acc(grads, f"embeddings.{i}.pos_embed", dh.sum(0, keepdim=True))
             _acc(grads, f"embeddings.{i}.cls_token", dh[:, 0].sum(0).reshape(1, 1, D))

@@ -69,6 +69,9 @@ CASES = {
     "txtcls_aux": dict(mk=dict(modalities=[None, "txt"], num_classes=[None, 4], tasks=[None, "cls"], embed_dim=64, depth=2,
                                num_heads=1, vocab_size=64, max_text_len=16, with_aux=True, aux_trained=False),
                        B=4, seq=12, kind="txt", full=False),
+    # colearn_param == 'attn' (mome.py:836-840): the text tower's Attention modules are the image tower's
+    "colearn_attn": dict(mk=dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=64, depth=2,
+                                 num_heads=1, vocab_size=64, max_text_len=16, colearn_param="attn"), B=4, seq=16, kind="img+txt", full=False),
 }
 
 
@@ -271,7 +274,7 @@ def sampling_case():
 def init_case():
     recs = []
     for name, mk in [("toy", CASES["toy"]["mk"]), ("small", CASES["small"]["mk"]), ("imgcls_aux", CASES["imgcls_aux"]["mk"]),
-                     ("txtcls_aux", CASES["txtcls_aux"]["mk"])]:
+                     ("txtcls_aux", CASES["txtcls_aux"]["mk"]), ("colearn_attn", CASES["colearn_attn"]["mk"])]:
         torch.manual_seed(1234)
         m = ref.mome.ModalityAgnosticTransformer(**mk)
         m.sync_shared_weights()
@@ -435,6 +438,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "split":
         split_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "colearn":
+        model_case("colearn_attn", CASES["colearn_attn"])
+        init_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "prox":
         update_prox_case()

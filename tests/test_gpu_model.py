@@ -9,7 +9,7 @@ from test_oracle_golden import cfg_from_mk
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["toy", "small", "imgcls_aux", "txtcls_aux"]
+CASES = ["toy", "small", "imgcls_aux", "txtcls_aux", "colearn_attn"]
 
 
 def grad_tol(k, go, grads_o, weights, rtol, atol):
@@ -24,7 +24,7 @@ def grad_tol(k, go, grads_o, weights, rtol, atol):
 
 def oracle_step(case, rec, dp_masks=None):
     cfg = cfg_from_mk(rec["mk"])
-    p = G.case_weights(case)
+    p = O.resolve_colearn(G.case_weights(case), cfg)
     img, ids, y = G.case_inputs(rec)
     batch = {"img+txt": ("img+txt", img, ids), "img": ("img", img, y), "txt": ("txt", ids, y)}[rec["kind"]]
     state = dict(step=0, m={}, v={})
@@ -171,3 +171,34 @@ def test_fused_optimizer_is_bit_identical_to_the_separate_one(tmp_path, kind):
             wa, wb = out["0"]["wc"][o:o + c], out["1"]["wc"][o:o + c]
             assert torch.equal(wa, wb), f"bf16 compute weights of {name}"
     assert n_lin > 0.8 * out["0"]["p"].numel()
+
+
+def test_colearn_attn_d384_bf16_shared_attention_gradients():
+    """colearn_param == 'attn' at the ViT-S width in the timed mode: the text tower's weight gradients of the shared qkv / proj go
+    through the 128x384 grouped kernel into the side buffer and are added to the image tower's; against the emulating oracle."""
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    from synth import det_state_dict
+    mk = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=384, depth=2, num_heads=6,
+              vocab_size=97, max_text_len=16, colearn_param="attn")
+    cfg = cfg_from_mk(mk)
+    torch.manual_seed(3)
+    ref = M(**mk)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    B, seq = 8, 16
+    g = torch.Generator().manual_seed(21)
+    img = (torch.randn(B, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1)
+    ids = torch.randint(1, 97, (B, seq), generator=g)
+    p = O.resolve_colearn({k: v.clone() for k, v in sd.items()}, cfg)
+    with O.emulate_bf16():
+        outs_o, cache = O.forward(p, cfg, [img, ids], feat_out=True)
+        loss_o, da, db = O.contrastive_loss(outs_o[0], outs_o[1])
+        grads_o = O.backward(p, cfg, cache, [da, db])
+    model = PU.build_product(mk, "bf16", sd)
+    model.train()
+    loss, grads, _ = PU.product_step(model, "img+txt", img, ids, None, 1e-4)
+    assert abs(loss - float(loss_o)) <= 3e-2 * max(1.0, abs(float(loss_o)))
+    for k in ("blockses.0.0.attn.qkv.weight", "blockses.0.1.attn.proj.weight", "blockses.0.1.attn.qkv.bias", "blockses.1.0.mlp.fc1.weight"):
+        go = grads_o[k]
+        rel = float((grads[k] - go).norm() / go.norm())
+        assert rel <= 8e-2, (k, rel)
+    assert "blockses.1.0.attn.qkv.weight" not in grads

@@ -163,7 +163,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fedcola_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.fc_abi_version() == 2
+    assert lib.fc_abi_version() == 3
 
 
 def test_model_layout_and_errors_without_gpu():
@@ -191,7 +191,7 @@ def test_header_is_plain_c(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     src = tmp_path / "t.c"
-    src.write_text('#include "fedcola_hip.h"\nint main(void) { fc_model_cfg c; (void)c; return FC_ABI_VERSION == 2 ? 0 : 1; }\n')
+    src.write_text('#include "fedcola_hip.h"\nint main(void) { fc_model_cfg c; (void)c; return FC_ABI_VERSION == 3 ? 0 : 1; }\n')
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -231,8 +231,10 @@ def test_scope_all_aliases_the_absent_tower_to_the_main_blocks():
     assert all(not k.startswith("blockses.1.") for k in m2.state_dict())
 
 
-def test_colearn_param_blocks_is_the_reference_noop_and_attn_is_loud():
-    """mome.py:832-835 rebinds a loop variable only ('blocks' shares nothing); :836-840 ('attn') really aliases modules."""
+def test_colearn_param_blocks_is_the_reference_noop_and_attn_shares_modules():
+    """mome.py:832-835 rebinds a loop variable only ('blocks' shares nothing); :836-840 ('attn') really aliases modules: the second
+    tower's attention keys are views of the main tower's tensors, named_parameters() lists them once (init.json pins key order,
+    parameter list and default init against the real reference)."""
     m = _toy(["img", "txt"], colearn_param="blocks")
     before = list(m.state_dict().keys())
     m.sync_shared_weights()
@@ -240,8 +242,19 @@ def test_colearn_param_blocks_is_the_reference_noop_and_attn_is_loud():
     sd = m.state_dict()
     assert sd["blockses.0.0.attn.qkv.weight"].data_ptr() != sd["blockses.1.0.attn.qkv.weight"].data_ptr()
     m = _toy(["img", "txt"], colearn_param="attn")
-    with pytest.raises(NotImplementedError):
-        m.sync_shared_weights()
+    m.sync_shared_weights()
+    sd = m.state_dict()
+    for nm in ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias"):
+        assert sd[f"blockses.0.0.{nm}"].data_ptr() == sd[f"blockses.1.0.{nm}"].data_ptr()
+    assert sd["blockses.0.0.mlp.fc1.weight"].data_ptr() != sd["blockses.1.0.mlp.fc1.weight"].data_ptr()
+    names = [k for k, _ in m.named_parameters()]
+    assert "blockses.0.0.attn.qkv.weight" in names and "blockses.1.0.attn.qkv.weight" not in names
+    keys = list(sd.keys())
+    assert keys.index("blockses.1.0.norm1.bias") < keys.index("blockses.1.0.attn.qkv.weight") < keys.index("blockses.1.0.norm2.weight")
+    # load_state_dict: the later key wins, like the reference's key-by-key copy into one shared tensor
+    new = {k: torch.full_like(v, 2.0 if k.startswith("blockses.1.") else 1.0) for k, v in sd.items()}
+    m.load_state_dict(new)
+    assert float(m.state_dict()["blockses.0.0.attn.qkv.weight"].mean()) == 2.0
 
 
 def test_pretrain_vit_key_mapping_on_a_synthetic_timm_state_dict():

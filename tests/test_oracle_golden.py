@@ -10,14 +10,14 @@ def cfg_from_mk(mk):
     return O.OracleCfg(modalities=tuple(mk["modalities"]), tasks=tuple(mk["tasks"]), num_classes=tuple(mk["num_classes"]),
                        D=mk["embed_dim"], depth=mk["depth"], heads=mk["num_heads"], vocab=mk["vocab_size"],
                        max_text_len=mk["max_text_len"], with_aux=mk.get("with_aux", False),
-                       aux_trained=mk.get("aux_trained", False))
+                       aux_trained=mk.get("aux_trained", False), colearn_attn=mk.get("colearn_param", "none") == "attn")
 
 
-@pytest.mark.parametrize("case", ["toy", "small", "imgcls_aux", "txtcls_aux"])
+@pytest.mark.parametrize("case", ["toy", "small", "imgcls_aux", "txtcls_aux", "colearn_attn"])
 def test_model_case(case):
     rec = G.load(f"model_{case}.json")
     cfg = cfg_from_mk(rec["mk"])
-    p = G.case_weights(case)
+    p = O.resolve_colearn(G.case_weights(case), cfg)
     img, ids, y = G.case_inputs(rec)
     kind = rec["kind"]
     batch = {"img+txt": ("img+txt", img, ids), "img": ("img", img, y), "txt": ("txt", ids, y)}[kind]
