@@ -200,6 +200,30 @@ def test_vit_s_b64_bf16_layer_by_layer():
     print("layer-by-layer worst:", worst)
 
 
+def test_vit_b_full_depth_bf16_layer_by_layer():
+    """BASELINE.json config[3]'s model at its stated size -- ViT-B/16 + BERT-base width (768 wide, 12 layers, 12 heads, vocab 30 522,
+    40-token captions), img+txt client, B = 32 -- teacher-forced per layer against the emulating oracle (first and last layer of
+    each tower), plus the loss from the library's own features."""
+    mk = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=768, depth=12, num_heads=12,
+              vocab_size=30522, max_text_len=40)
+    sd = _default_init(mk, 11)
+    B, seq, D, H, depth = 32, 40, 768, 12, 12
+    img, ids = _batch(B, seq, 30522, seed=77)
+    model = PU.build_product(mk, "bf16", sd)
+    model.train()
+    loss, grads, _ = PU.product_step(model, "img+txt", img, ids, None, 1e-4)
+    worst = ("", 0.0)
+    for tower, N, layers in ((0, 197, (0, 11)), (1, seq, (0, 11))):
+        for l in layers:
+            w = _layer_local(model, sd, grads, B, seq, tower, N, l, D, H)
+            if w[1] > worst[1]:
+                worst = w
+    outs = [_ws_tensor(model, B, seq, tower, 0, "out", (B, D), torch.float32) for tower in (0, 1)]
+    loss_o, _, _ = O.contrastive_loss(outs[0], outs[1])
+    assert abs(loss - float(loss_o)) <= 1e-5 * max(1.0, abs(float(loss_o)))
+    print("ViT-B layer-by-layer worst:", worst)
+
+
 def test_vit_s_bf16_droppath_masks_vs_emulating_oracle():
     """The bf16 drop-path epilogue (EPI_RES_SCALE) and the scaled backward, reference default --dropout 0.1 (timm DropPath,
     mome.py:213,223,726-728), with host-drawn masks handed to both sides."""
