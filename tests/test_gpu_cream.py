@@ -247,3 +247,52 @@ def test_two_epochs_uni_modal_uses_per_parameter_steps():
         assert (sd[k].cpu() - v).abs().max() <= 6e-3, k
     # the head really lagged: a fused global-step run would have used step 6 for its second-epoch updates
     assert float((sd["heads.0.head.weight"].cpu() - p["heads.0.head.weight"]).abs().max()) <= 2e-3
+
+
+def test_mm_client_at_vit_s_width_bf16_vs_emulating_oracle():
+    """BASELINE.json config[4]'s client in the timed mode: an img+txt CreamFL client at the ViT-S width (384, 6 heads; 2 layers) in
+    bf16 -- local contrastive epoch + public-set distillation (moon / inter losses on bf16 features, clip, AdamW) -- against the
+    oracle emulating the kernels' bf16 rounding.  AdamW normalises the step, so the weights are compared through the size of the
+    update (|dp| <= 1.5 lr per step) and through the agreement of its direction where the oracle's update is not marginal."""
+    from fedcola_amd.client.creamflclient import CreamflClient
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    from oracle import mome_oracle as O
+    from test_oracle_golden import cfg_from_mk
+    mk = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=384, depth=2, num_heads=6,
+              vocab_size=CU.VOCAB, max_text_len=CU.SEQ)
+    a = dict(CU.CREAM_ARGS)
+    args = RefArgs(precision="bf16", **a)
+    ds, pub = CU.Pairs(), CU.PubSet()
+    cl = CreamflClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "x", "cuda"
+    cl.pub_dataset = pub
+    g = torch.Generator().manual_seed(5)
+    gi = torch.nn.functional.normalize(torch.randn(len(pub), 384, generator=g), dim=-1)
+    gt = torch.nn.functional.normalize(torch.randn(len(pub), 384, generator=g), dim=-1)
+    cl.global_img_feature, cl.global_txt_feature = gi.cuda(), gt.cuda()
+    cl.distill_index = [pub.index[i] for i in range(len(pub))]
+    torch.manual_seed(4)
+    sd0 = {k: v.clone() for k, v in M(**mk).state_dict().items()}
+    m = M(precision="bf16", init=False, **mk)
+    m.load_state_dict(sd0)
+    cl.model = m.cuda()
+    res = cl.update()
+    p = {k: v.clone() for k, v in sd0.items()}
+    pubs = [(pub.img[s:s + 4], pub.ids[s:s + 4], pub.index[s:s + 4]) for s in range(0, len(pub), 4)]
+    tb = [("img+txt", ds.img[s:s + 4], ds.ids[s:s + 4]) for s in range(0, len(ds), 4)]
+    with O.emulate_bf16():
+        exp = CO.client_update(p, cfg_from_mk(mk), "img+txt", tb, pubs, [int(i) for i in pub.index], gi, gt, E=1, lr=a["lr"],
+                               interintra_weight=a["interintra_weight"], n_train=len(ds))
+    assert abs(res[1]["loss"] - exp[1]) <= 3e-2 * max(1.0, abs(exp[1]))
+    steps = len(tb) + len(pubs)
+    sd = cl.model.state_dict()
+    agree = total = 0
+    for k, v in p.items():
+        if not v.dtype.is_floating_point or k.endswith("attn.qkv.bias"):
+            continue
+        got, d_o = sd[k].cpu(), v - sd0[k]
+        assert float((got - sd0[k]).abs().max()) <= 1.5 * a["lr"] * steps, k
+        sel = d_o.abs() >= 0.5 * a["lr"] * steps                      # elements the oracle moved decisively
+        agree += int((torch.sign(got - sd0[k])[sel] == torch.sign(d_o)[sel]).sum())
+        total += int(sel.sum())
+    assert total > 1000 and agree >= 0.97 * total, (agree, total)
