@@ -683,6 +683,15 @@ static int check_device(const void* p, const char* what) {
     (void)hipGetLastError();
   return 0;
 }
+#ifdef FC_PROBES
+// tools build (FC_STEP_PHASES=1): when each internal stream finished its part of the forward / backward, before the joins
+static hipEvent_t g_stream_ev[64 * 8];
+static bool g_stream_on = false;
+static int g_stream_step = 0;
+#define FC_STREAM_EV(i, st) do { if (g_stream_on) (void)hipEventRecord(g_stream_ev[(g_stream_step & 63) * 8 + (i)], (st)); } while (0)
+#else
+#define FC_STREAM_EV(i, st) do {} while (0)
+#endif
 static int ensure_tables(const fc_model* m, const Ws& w, hipStream_t s, FcTnProblem** probs, FcLnReduce** lntab) {
   const size_t need_p = sizeof(FcTnProblem) * (size_t)w.max_probs, need = need_p + sizeof(FcLnReduce) * (size_t)w.max_ln;
   if (m->tables_bytes < need) {      // first backward of this handle (or a deeper model than before): one small allocation, kept
@@ -731,6 +740,7 @@ static int forward_impl(const fc_model* m, const float* params, const void* wc, 
     } else {
       FC_TRY(tower_forward(c, w, 0, img, nullptr, feat_out, out_img));
     }
+    FC_STREAM_EV(0, m->side); FC_STREAM_EV(1, m->mbs[0]); FC_STREAM_EV(2, s);
     FC_TRY(join_side(m, s));
     return 0;
   }
@@ -1037,6 +1047,7 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     } else {
       FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
     }
+    FC_STREAM_EV(3, m->side); FC_STREAM_EV(4, m->mbs[0]); FC_STREAM_EV(5, s);
     FC_TRY(join_side(m, s));
   } else {
     if (run0) FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
@@ -1056,6 +1067,7 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
   }
   if (!probs.empty()) {   // every chunk was launched by flush_dw; the main stream continues after the last one
     FC_CHECK_HIP(hipEventRecord(m->ev_dw_out, m->dws));
+    FC_STREAM_EV(6, m->dws);
     if (late && late->fused) late->pending = true;                                       // the caller waits for ev_dw_out itself, later
     else if (late && late->pending) FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_prev, 0));   // ... likewise, after the first optimizer phase
     else FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
@@ -1285,7 +1297,12 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
 #ifdef FC_PROBES
 #define FC_PHASE(i) do { if (g_phase_on) (void)hipEventRecord(g_phase_ev[(step & 63) * 5 + (i)], s); } while (0)
   static const bool g_phase_env = getenv("FC_STEP_PHASES") != nullptr;
-  if (g_phase_env && !g_phase_on) { for (int i = 0; i < 64 * 5; ++i) (void)hipEventCreate(&g_phase_ev[i]); g_phase_on = true; }
+  if (g_phase_env && !g_phase_on) {
+    for (int i = 0; i < 64 * 5; ++i) (void)hipEventCreate(&g_phase_ev[i]);
+    for (int i = 0; i < 64 * 8; ++i) (void)hipEventCreate(&g_stream_ev[i]);
+    g_phase_on = g_stream_on = true;
+  }
+  g_stream_step = step;
 #else
 #define FC_PHASE(i) do {} while (0)
 #endif
@@ -1353,6 +1370,17 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
   return 0;
 }
 #ifdef FC_PROBES
+// tools build only: ms from the start of `step` to the end of each internal stream's part: [0..2] forward text / chain 1 / chain 0,
+// [3..5] backward text / chain 1 / chain 0, [6] last weight-gradient chunk
+extern "C" int fc_dbg_stream_events(int step, float* ms7) {
+  if (!g_stream_on) return -1;
+  hipEvent_t e0 = g_phase_ev[(step & 63) * 5];
+  for (int i = 0; i < 7; ++i) {
+    (void)hipEventSynchronize(g_stream_ev[(step & 63) * 8 + i]);
+    (void)hipEventElapsedTime(ms7 + i, e0, g_stream_ev[(step & 63) * 8 + i]);
+  }
+  return 0;
+}
 // tools build only (FC_STEP_PHASES=1): GPU time of the last step's phases on the caller's stream: forward, loss, backward (up to the
 // late weight-gradient chunk), optimizer tail
 extern "C" int fc_dbg_step_phases(int step, float* ms5) {     // [0..3] phases of `step`, [4] gap from the previous step's end to this step's start

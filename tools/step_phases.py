@@ -29,5 +29,12 @@ for k in range(W + 1, W + steps + 1):        # steady state: no synchronisation 
     raw.fc_dbg_step_phases(k, out)
     acc += np.array(list(out))
 acc /= steps
+ev = np.zeros(7); o7 = (C.c_float * 7)()
+for k in range(W + 1, W + steps + 1):
+    raw.fc_dbg_stream_events(k, o7)
+    ev += np.array(list(o7))
+ev /= steps
+print("ms from step start to the end of each stream's part: forward text %.3f  chain1 %.3f  chain0 %.3f | backward text %.3f  chain1 %.3f  chain0 %.3f | last dW chunk %.3f"
+      % tuple(ev))
 print("steady-state phases (ms): forward %.3f  loss %.3f  backward %.3f  optimizer+late dW %.3f  idle gap before the step %.3f  -> %.3f per step"
       % (*acc, acc.sum()))
