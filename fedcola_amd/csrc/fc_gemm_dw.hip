@@ -272,6 +272,208 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dw_wide(const FcTnProblem* __re
   }
 }
 
+// ======================================================================== loader / consumer form (FC_DW_WIDE=2)
+// Same tile, same LDS images, 640 threads: waves 0-7 only read fragments and issue MFMAs, waves 8-9 only move data, by LDS-DMA
+// (buffer_load ... lds: no staging registers, no ds_write).  In the 8-wave form every wave issues its loads, computes, then writes
+// LDS, and the three phases run back to back (3 600 cycles per k-tile for 1 536 of MFMA); here the DMA issue (32 x ~42 cycles per
+// loader wave) and the landing of the next k-tile run under the consumers' MFMAs, one barrier per k-tile.
+//   LDS-DMA fills a 1-KB piece (4 k rows x 256 B) linearly, lane L -> byte 16 L, so the kr_off swizzle is applied to the SOURCE:
+//   lane (kq = L >> 4, pc = L & 15) fetches logical chunk c = (((pc >> 1) ^ s) << 1) | (pc & 1) of row 4p + kq, s = s(4p + kq); s only
+//   depends on kq and on bit 1 of p, so two per-lane offsets per operand serve all 16 pieces of an image.
+// Measured: 249 vs 293 us per tile stand-alone (one problem, idle chip), but 5.12-5.22 vs 5.07-5.14 ms in the client step, also with every
+// weight gradient in the un-overlapped tail (FC_DW_FLUSH=12): with two LDS buffers only ONE k-tile of DMA can be in flight and it drains
+// at every barrier, which tolerates the loaded chip's memory latency worse than the 8-wave form's two k-tiles of register loads.  Kept as an
+// opt-in (FC_DW_WIDE=2, parity-tested); the next step would be 32-row stages in a four-slot ring with a counted vmcnt.
+// The bias gradient comes from the dY fragments of the wn == 0 consumer waves: a lane holds 8 k values of one column,
+// v_dot2c_f32_bf16 against (1, 1) adds two at a time.
+typedef __attribute__((ext_vector_type(2))) __bf16 dws_bf16x2;
+__device__ __forceinline__ float dws_sum8(const bf16x8& f, float acc) {
+  const dws_bf16x2 one = __builtin_bit_cast(dws_bf16x2, 0x3F803F80u);
+  const uint4 u = __builtin_bit_cast(uint4, f);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dws_bf16x2, u.x), one, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dws_bf16x2, u.y), one, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dws_bf16x2, u.z), one, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dws_bf16x2, u.w), one, acc, false);
+  return acc;
+}
+template <int KS>
+__device__ __forceinline__ void dws_kstep(unsigned lb, unsigned po, const DwKeys& kx, f32x4 (&acc)[4][6], float (&cs4)[4], bool colsum) {
+  bf16x8 af[4], b0[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af[i] = dw_frag<KS>(lb, kx.a[i] | po);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) b0[j] = dw_frag<KS>(lb, kx.b[j] | po);
+  frag_fence(af);
+  frag_fence3(b0);
+  bf16x8 b1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) b1[j] = dw_frag<KS>(lb, kx.b[3 + j] | po);     // in flight under the first 12 MFMAs
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], af[i], acc[i][j], 0, 0, 0);
+  if (colsum) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs4[i] = dws_sum8(af[i], cs4[i]);
+  }
+  frag_fence3(b1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][3 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], af[i], acc[i][3 + j], 0, 0, 0);
+}
+
+template <bool OPT>
+__global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 8;
+  const int wm = (wave >> 2) & 1, wn = wave & 3;
+  const int idx = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+  while (pi + 1 < nprob && probs[pi + 1].tile_start <= idx) ++pi;
+  const FcTnProblem P = probs[pi];
+  const int local = idx - P.tile_start;
+  const int tile_m = local / P.tiles_n, tile_n = local % P.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * DW_BN;
+  const int M = P.M, N = P.N, K = P.K;
+  const bool do_colsum = (tile_n == 0) && (P.bias_grad != nullptr);
+  const int T = (K + BK - 1) / BK;
+  f32x4 acc[4][6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float cs4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (loader) {
+    const DwOperand oa = dw_operand(P.A, P.lda, M, K), ob = dw_operand(P.B, P.ldb, N, K);
+    const int lw = wave - 8, kq = lane >> 4, pc = lane & 15;
+    unsigned vA[2], vB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int sw = (h << 2) | kq;                           // s(k) of k = 4p + kq with bit 1 of p = h
+      const int col = ((((pc >> 1) ^ sw) << 1) | (pc & 1)) * 8;
+      vA[h] = (m0 + col < M) ? (unsigned)(((long)kq * P.lda + m0 + col) * 2) : FC_OOB;
+      vB[h] = (unsigned)(((long)kq * P.ldb + n0 + col) * 2);
+    }
+    // one k-tile = 64 pieces of 1 KB; loader wave lw moves images 2 lw and 2 lw + 1 (16 pieces each): a running scalar offset per
+    // image (+ 4 rows per piece) instead of 64 precomputed ones, which hipcc would hoist out of the loop and spill
+    const unsigned rowA4 = (unsigned)__builtin_amdgcn_readfirstlane((int)(4u * oa.kstride));
+    const unsigned rowB4 = (unsigned)__builtin_amdgcn_readfirstlane((int)(4u * ob.kstride));
+#define DWS_ISSUE(t, b)                                                                                                      \
+  do {                                                                                                                       \
+    _Pragma("unroll") for (int im = 0; im < 2; ++im) {                                                                        \
+      const int img = 2 * lw + im;                                                                                           \
+      unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((t) * BK) * (img == 0 ? oa.kstride : ob.kstride))) + \
+                    (img == 0 ? 0u : 256u * (unsigned)(img - 1));                                                            \
+      char* dst = smem + (b) * DW_STAGE + img * 16384;                                                                        \
+      _Pragma("unroll") for (int p = 0; p < 16; ++p) {                                                                        \
+        const int h = (p >> 1) & 1;                                                                                          \
+        if (img == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(oa.rsrc, (lds_ptr_t)(dst + p * 1024), 16, vA[h], so, 0, 0);     \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(ob.rsrc, (lds_ptr_t)(dst + p * 1024), 16, vB[h], so, 0, 0);             \
+        so += (img == 0 ? rowA4 : rowB4);                                                                                    \
+      }                                                                                                                      \
+    }                                                                                                                        \
+  } while (0)
+    DWS_ISSUE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) {
+        if (t & 1) DWS_ISSUE(t + 1, 0); else DWS_ISSUE(t + 1, 1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#undef DWS_ISSUE
+  } else {
+    unsigned lb;
+    DwKeys kx;
+    {
+      const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+      const int gq = lane >> 4, ii = lane & 15, q = ii >> 2, pp = ii & 3;
+      const int sw = ((gq & 1) << 2) | q;
+      lb = lds0 + (unsigned)((8 * gq + q) * 256 + (sw << 5) + ((pp >> 1) << 4) + (pp & 1) * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kx.a[i] = (unsigned)__builtin_amdgcn_readfirstlane((wm * 4 + i) << 5);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int u = wn * 6 + j;
+        kx.b[j] = (unsigned)__builtin_amdgcn_readfirstlane(((u & 7) << 5) | (16384 * (1 + (u >> 3))));
+      }
+    }
+    const bool colsum = do_colsum && wn == 0;
+    __builtin_amdgcn_s_barrier();                              // k-tile 0 has landed
+    for (int t = 0; t < T; ++t) {
+      const unsigned po = (t & 1) ? (unsigned)DW_STAGE : 0u;
+      dws_kstep<0>(lb, po, kx, acc, cs4, colsum);
+      dws_kstep<1>(lb, po, kx, acc, cs4, colsum);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of this buffer is done before it is refilled
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  // ---- bias gradient: a wn == 0 consumer lane (g = lane >> 4, r = lane & 15) holds, per row block i, the sum over its k values of
+  // dY column 64 wm + 16 i + r; the four g meet in LDS
+  float* Rd = (float*)smem;                                    // [128 cols][4 g]
+  if (!loader && do_colsum && wn == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Rd[(wm * 64 + i * 16 + (lane & 15)) * 4 + (lane >> 4)] = cs4[i];
+  }
+  lds_barrier();
+  if (do_colsum && tid < 128 && m0 + tid < M) {
+    const float sum = Rd[tid * 4] + Rd[tid * 4 + 1] + Rd[tid * 4 + 2] + Rd[tid * 4 + 3];
+    P.bias_grad[m0 + tid] = sum;
+    if (OPT) {
+      const size_t ix = (size_t)(P.bias_grad + m0 + tid - o.g0);
+      float pp = o.p[ix], mm = o.m[ix], vv = o.v[ix];
+      fc_adamw_elem(pp, sum, mm, vv, o.decay, o.beta1, o.beta2, o.eps, o.step_size, o.inv_bc2_sqrt);
+      o.p[ix] = pp; o.m[ix] = mm; o.v[ix] = vv;
+      if (o.shadow) o.shadow[ix] = f2bf(pp);
+    }
+  }
+  lds_barrier();
+  // ---- output (consumer threads 0..511; the loader waves only keep the barrier count)
+  float* Cs = (float*)smem;
+  const int g = lane >> 4, cl = lane & 15;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (!loader && wm == h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          *(float4*)(Cs + (i * 16 + cl) * DW_LD + wn * 96 + j * 16 + 4 * g) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+    lds_barrier();
+    if (!loader) {
+#pragma unroll 4
+      for (int q = 0; q < 12; ++q) {
+        const int f = tid + 512 * q, row = f / 96, c4 = (f % 96) * 4;
+        const int m = m0 + 64 * h + row, n = n0 + c4;
+        if (m < M && n < N) {
+          float* dst = P.C + (size_t)m * P.ldc + n;
+          float4 gv = *(const float4*)(Cs + row * DW_LD + c4);
+          *(float4*)dst = gv;
+          if (OPT) {
+            const size_t ix = (size_t)(dst - o.g0);
+            float4 pp = *(const float4*)(o.p + ix), mm = *(const float4*)(o.m + ix), vv = *(const float4*)(o.v + ix);
+            float* Pp = (float*)&pp; float* G = (float*)&gv; float* Mm = (float*)&mm; float* V = (float*)&vv;
+            bf16_t sh[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              fc_adamw_elem(Pp[k], G[k], Mm[k], V[k], o.decay, o.beta1, o.beta2, o.eps, o.step_size, o.inv_bc2_sqrt);
+              sh[k] = f2bf(Pp[k]);
+            }
+            *(float4*)(o.p + ix) = pp; *(float4*)(o.m + ix) = mm; *(float4*)(o.v + ix) = vv;
+            if (o.shadow) *(uint2*)(o.shadow + ix) = *(const uint2*)sh;
+          }
+        }
+      }
+    }
+    lds_barrier();
+  }
+}
+
 int fc_gemm_dw_wide_supported(const FcTnProblem& p) {
   static const int on = getenv("FC_DW_WIDE") ? atoi(getenv("FC_DW_WIDE")) : 1;
   if (!on) return 0;
@@ -283,7 +485,7 @@ int fc_gemm_dw_wide_tiles(const FcTnProblem& p, int* tiles_n) {
   *tiles_n = fc_cdiv(p.N, DW_BN);
   return fc_cdiv(p.M, BM) * *tiles_n;
 }
-int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s, const FcAdamW* opt) {
+int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s, const FcAdamW* opt, int form_arg) {
   if (nprob <= 0 || total_tiles <= 0) return 0;
   const int lds = 2 * DW_STAGE;
   static bool done = false;
@@ -291,6 +493,20 @@ int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hi
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
+  }
+  static const int form_env = getenv("FC_DW_WIDE") ? atoi(getenv("FC_DW_WIDE")) : 1;      // 1: 8 waves, 2: 8 consumer + 2 loader waves
+  const int form = form_arg ? form_arg : form_env;
+  if (form == 2) {
+    static bool done2 = false;
+    if (!done2) {
+      FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      done2 = true;
+    }
+    if (opt) hipLaunchKernelGGL(k_gemm_dw_spec<true>, dim3(total_tiles), dim3(640), lds, s, probs_dev, nprob, *opt);
+    else hipLaunchKernelGGL(k_gemm_dw_spec<false>, dim3(total_tiles), dim3(640), lds, s, probs_dev, nprob, FcAdamW());
+    FC_LAUNCH_CHECK();
+    return 0;
   }
   if (opt) hipLaunchKernelGGL(k_gemm_dw_wide<true>, dim3(total_tiles), dim3(512), lds, s, probs_dev, nprob, *opt);
   else hipLaunchKernelGGL(k_gemm_dw_wide<false>, dim3(total_tiles), dim3(512), lds, s, probs_dev, nprob, FcAdamW());

@@ -140,7 +140,8 @@ int fc_gemm_tn_grouped_supported(const FcTnProblem& p);
 // 128 x 384 tiles for problems whose N (the linear's `in`) is a multiple of 384 (fc_gemm_dw.hip): same table format, own tile numbering
 int fc_gemm_dw_wide_supported(const FcTnProblem& p);
 int fc_gemm_dw_wide_tiles(const FcTnProblem& p, int* tiles_n);
-int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s, const struct FcAdamW* opt = nullptr);
+// form: 1 = 8 waves that load, compute and store; 2 = 8 consumer + 2 loader (LDS-DMA) waves; 0 = FC_DW_WIDE / default
+int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s, const struct FcAdamW* opt = nullptr, int form = 0);
 // opt != null: the epilogue also takes the AdamW step of every element it produced (dW tiles and the bias gradients), so the
 // optimizer needs no pass of its own over the linears' weights; the gradient is still stored
 int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s, const FcAdamW* opt = nullptr);

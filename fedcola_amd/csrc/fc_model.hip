@@ -1531,7 +1531,7 @@ extern "C" int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, f
   FcTnProblem* dev = nullptr;
   FC_CHECK_HIP(hipMalloc(&dev, sizeof(p)));
   FC_CHECK_HIP(hipMemcpy(dev, &p, sizeof(p), hipMemcpyHostToDevice));
-  int r = wide ? fc_gemm_dw_wide(dev, 1, tiles, (hipStream_t)stream) : fc_gemm_tn_grouped(dev, 1, tiles, (hipStream_t)stream);
+  int r = wide ? fc_gemm_dw_wide(dev, 1, tiles, (hipStream_t)stream, nullptr, wide) : fc_gemm_tn_grouped(dev, 1, tiles, (hipStream_t)stream);
   FC_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
   FC_CHECK_HIP(hipFree(dev));
   return r;

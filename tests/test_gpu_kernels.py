@@ -113,7 +113,7 @@ def test_gemm(impl, kind, prec, M, N, K):
         assert err <= t * max(1.0, scale), (err, scale, out_dt)
 
 
-@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("wide", [0, 1, 2])
 @pytest.mark.parametrize("rows,out,inn", [(197 * 4, 384, 384), (1000, 1152, 384), (64 * 5 + 17, 1536, 384), (2048, 384, 1536), (777, 200, 768),
                                           (12608, 384, 384)])
 def test_grouped_weight_gradient_kernels(wide, rows, out, inn):

@@ -41,5 +41,5 @@ run("ln bwd partial", lambda: _lib.check(L.fc_k_layernorm_bwd_partial(1, P(dy), 
 for name, out, inn in (("dW qkv", 1152, 384), ("dW proj", 384, 384), ("dW fc1", 1536, 384), ("dW fc2", 384, 1536)):
     dYm, Xm = bf(M, out), bf(M, inn)
     dWm, dbm = torch.empty(out, inn, device="cuda"), torch.empty(out, device="cuda")
-    for wide in (0, 1):
+    for wide in (0, 1, 2):
         run(f"{name} wide={wide}", lambda: _lib.check(L.fc_k_dw(wide, P(dYm), P(Xm), P(dWm), P(dbm), M, out, inn, sp)))
