@@ -11,9 +11,12 @@
  * Allocation / synchronisation: the steady state (same handle, same workspace address, same batch shape) allocates nothing
  * and never blocks the host.  The exceptions, each once: the first forward of a process creates the library's internal HIP
  * streams for the device and measures which of them run concurrently (~10 ms); the first backward of a handle allocates its
- * table buffer (< 64 KB, freed by fc_model_destroy); a call whose workspace address or batch shape differs from the previous
- * one re-sends those tables (one stream synchronisation); fc_prox_term / fc_clip_grad_norm copy a <= 50-KB table from host
- * memory on every call (their scratch is the caller's and may have been reused in between).
+ * table buffers (weight-gradient problems, LayerNorm reductions; the first fc_client_step also the optimizer's chunk table, a
+ * colearn_attn model the shared-gradient chunk table: < 64 KB each, one device synchronisation, freed by fc_model_destroy); a call
+ * whose workspace address or batch shape differs from the previous one re-sends those tables (one stream synchronisation);
+ * fc_prox_term / fc_clip_grad_norm copy a <= 50-KB table from host memory on every call (their scratch is the caller's and may
+ * have been reused in between); fc_comm_create builds an RCCL communicator; the fc_k_* test entry points synchronise where their
+ * comment says so.
  */
 #ifndef FEDCOLA_HIP_H
 #define FEDCOLA_HIP_H
