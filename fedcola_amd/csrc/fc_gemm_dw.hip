@@ -272,18 +272,18 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dw_wide(const FcTnProblem* __re
   }
 }
 
-// ======================================================================== loader / consumer form (FC_DW_WIDE=2)
-// Same tile, same LDS images, 640 threads: waves 0-7 only read fragments and issue MFMAs, waves 8-9 only move data, by LDS-DMA
-// (buffer_load ... lds: no staging registers, no ds_write).  In the 8-wave form every wave issues its loads, computes, then writes
-// LDS, and the three phases run back to back (3 600 cycles per k-tile for 1 536 of MFMA); here the DMA issue (32 x ~42 cycles per
-// loader wave) and the landing of the next k-tile run under the consumers' MFMAs, one barrier per k-tile.
+// ======================================================================== loader / consumer form (default; FC_DW_WIDE=1 selects the 8-wave form)
+// Same tile, same image layout, 640 threads: waves 0-7 only read fragments and issue MFMAs, waves 8-9 only move data, by LDS-DMA
+// (buffer_load ... lds: no staging registers, no ds_write), in stages of 32 k rows through a four-slot ring (4 x 32 KB): the loaders
+// run up to three stages ahead and wait with a counted vmcnt(32), so DMA is in flight all the time; one barrier per stage.
+//   Measured (tools/kernel_bench.py under rocprofv3, one tile per CU): 207 us per tile = 1.05 us per 64 k rows = 26 B/clk per CU, at
+//   the ~30 B/clk vector-memory -> LDS ceiling, against 293 us for the 8-wave form (load, compute, store back to back); client step
+//   5.07 -> 4.98 ms on the same box.  A first version with two 64-row buffers (ONE k-tile of DMA in flight, drained at every barrier)
+//   was faster stand-alone (249 us) but SLOWER in the step (5.12-5.22 ms, also with every weight gradient in the un-overlapped
+//   tail): what counts on the loaded chip is how many bytes stay in flight across the barriers.
 //   LDS-DMA fills a 1-KB piece (4 k rows x 256 B) linearly, lane L -> byte 16 L, so the kr_off swizzle is applied to the SOURCE:
 //   lane (kq = L >> 4, pc = L & 15) fetches logical chunk c = (((pc >> 1) ^ s) << 1) | (pc & 1) of row 4p + kq, s = s(4p + kq); s only
-//   depends on kq and on bit 1 of p, so two per-lane offsets per operand serve all 16 pieces of an image.
-// Measured: 249 vs 293 us per tile stand-alone (one problem, idle chip), but 5.12-5.22 vs 5.07-5.14 ms in the client step, also with every
-// weight gradient in the un-overlapped tail (FC_DW_FLUSH=12): with two LDS buffers only ONE k-tile of DMA can be in flight and it drains
-// at every barrier, which tolerates the loaded chip's memory latency worse than the 8-wave form's two k-tiles of register loads.  Kept as an
-// opt-in (FC_DW_WIDE=2, parity-tested); the next step would be 32-row stages in a four-slot ring with a counted vmcnt.
+//   depends on kq and on bit 1 of p, so two per-lane offsets per operand serve all pieces of an image.
 // The bias gradient comes from the dY fragments of the wn == 0 consumer waves: a lane holds 8 k values of one column,
 // v_dot2c_f32_bf16 against (1, 1) adds two at a time.
 typedef __attribute__((ext_vector_type(2))) __bf16 dws_bf16x2;
@@ -323,6 +323,7 @@ __device__ __forceinline__ void dws_kstep(unsigned lb, unsigned po, const DwKeys
     for (int j = 0; j < 3; ++j) acc[i][3 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], af[i], acc[i][3 + j], 0, 0, 0);
 }
 
+#define DWS_SLOT 32768   // one stage: 4 images of [32 k][128 cols]
 template <bool OPT>
 __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
   const int m0 = tile_m * BM, n0 = tile_n * DW_BN;
   const int M = P.M, N = P.N, K = P.K;
   const bool do_colsum = (tile_n == 0) && (P.bias_grad != nullptr);
-  const int T = (K + BK - 1) / BK;
+  const int S = (K + 31) / 32;                                 // stages
   f32x4 acc[4][6];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -356,18 +357,18 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
       vA[h] = (m0 + col < M) ? (unsigned)(((long)kq * P.lda + m0 + col) * 2) : FC_OOB;
       vB[h] = (unsigned)(((long)kq * P.ldb + n0 + col) * 2);
     }
-    // one k-tile = 64 pieces of 1 KB; loader wave lw moves images 2 lw and 2 lw + 1 (16 pieces each): a running scalar offset per
-    // image (+ 4 rows per piece) instead of 64 precomputed ones, which hipcc would hoist out of the loop and spill
+    // one stage = 32 pieces of 1 KB; loader wave lw moves images 2 lw and 2 lw + 1 (8 pieces each): a running scalar offset per image
+    // (+ 4 rows per piece) instead of precomputed ones, which hipcc would hoist out of the loop and spill
     const unsigned rowA4 = (unsigned)__builtin_amdgcn_readfirstlane((int)(4u * oa.kstride));
     const unsigned rowB4 = (unsigned)__builtin_amdgcn_readfirstlane((int)(4u * ob.kstride));
-#define DWS_ISSUE(t, b)                                                                                                      \
+#define DWS_ISSUE(st)                                                                                                        \
   do {                                                                                                                       \
     _Pragma("unroll") for (int im = 0; im < 2; ++im) {                                                                        \
       const int img = 2 * lw + im;                                                                                           \
-      unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((t) * BK) * (img == 0 ? oa.kstride : ob.kstride))) + \
+      unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((st) * 32) * (img == 0 ? oa.kstride : ob.kstride))) + \
                     (img == 0 ? 0u : 256u * (unsigned)(img - 1));                                                            \
-      char* dst = smem + (b) * DW_STAGE + img * 16384;                                                                        \
-      _Pragma("unroll") for (int p = 0; p < 16; ++p) {                                                                        \
+      char* dst = smem + ((st) & 3) * DWS_SLOT + img * 8192;                                                                  \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                                         \
         const int h = (p >> 1) & 1;                                                                                          \
         if (img == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(oa.rsrc, (lds_ptr_t)(dst + p * 1024), 16, vA[h], so, 0, 0);     \
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(ob.rsrc, (lds_ptr_t)(dst + p * 1024), 16, vB[h], so, 0, 0);             \
@@ -375,16 +376,16 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
       }                                                                                                                      \
     }                                                                                                                        \
   } while (0)
-    DWS_ISSUE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // rows past K read as zeros (descriptor bounds), so stages past S may be issued freely: the counted wait stays uniform
+    DWS_ISSUE(0); DWS_ISSUE(1); DWS_ISSUE(2);
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");          // 16 per stage and wave: stage 0 has landed
     __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < T; ++t) {
-      if (t + 1 < T) {
-        if (t & 1) DWS_ISSUE(t + 1, 0); else DWS_ISSUE(t + 1, 1);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int st = 0; st < S; ++st) {
+      DWS_ISSUE(st + 3);                                       // slot (st + 3) & 3 = (st - 1) & 3: its readers passed the barrier above
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");        // stage st + 1 has landed (st + 2, st + 3 may still fly)
       __builtin_amdgcn_s_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the over-issued stages land before the epilogue reuses the LDS
 #undef DWS_ISSUE
   } else {
     unsigned lb;
@@ -399,19 +400,18 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const int u = wn * 6 + j;
-        kx.b[j] = (unsigned)__builtin_amdgcn_readfirstlane(((u & 7) << 5) | (16384 * (1 + (u >> 3))));
+        kx.b[j] = (unsigned)__builtin_amdgcn_readfirstlane(((u & 7) << 5) | (8192 * (1 + (u >> 3))));
       }
     }
     const bool colsum = do_colsum && wn == 0;
-    __builtin_amdgcn_s_barrier();                              // k-tile 0 has landed
-    for (int t = 0; t < T; ++t) {
-      const unsigned po = (t & 1) ? (unsigned)DW_STAGE : 0u;
-      dws_kstep<0>(lb, po, kx, acc, cs4, colsum);
-      dws_kstep<1>(lb, po, kx, acc, cs4, colsum);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of this buffer is done before it is refilled
+    __builtin_amdgcn_s_barrier();                              // stage 0 has landed
+    for (int st = 0; st < S; ++st) {
+      dws_kstep<0>(lb, (unsigned)((st & 3) * DWS_SLOT), kx, acc, cs4, colsum);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of this slot is done before it is refilled
       __builtin_amdgcn_s_barrier();
     }
   }
+  lds_barrier();                                               // loaders: vmcnt(0) above; nobody touches the ring any more
   // ---- bias gradient: a wn == 0 consumer lane (g = lane >> 4, r = lane & 15) holds, per row block i, the sum over its k values of
   // dY column 64 wm + 16 i + r; the four g meet in LDS
   float* Rd = (float*)smem;                                    // [128 cols][4 g]
@@ -494,7 +494,7 @@ int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hi
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
   }
-  static const int form_env = getenv("FC_DW_WIDE") ? atoi(getenv("FC_DW_WIDE")) : 1;      // 1: 8 waves, 2: 8 consumer + 2 loader waves
+  static const int form_env = getenv("FC_DW_WIDE") ? atoi(getenv("FC_DW_WIDE")) : 2;      // 1: 8 waves, 2: 8 consumer + 2 loader waves
   const int form = form_arg ? form_arg : form_env;
   if (form == 2) {
     static bool done2 = false;
