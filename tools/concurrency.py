@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """How many kernels run at once, from a rocprofv3 --kernel-trace csv of bench.py: share of the steady-state wall time with 0, 1, 2, ...
 kernels in flight, and the kernel time spent at each depth.  usage: tools/concurrency.py <dir> [first_step] [n_steps]
-(steps are delimited by the first k_patchify launch of each step: 2 launches per step, one per micro-batch chain)"""
+(steps are delimited by the first k_patchify launch of each step: 2 launches per step, one per micro-batch chain)
+Caveat: kernel tracing slows the host side of every launch; the traced step (7.5 ms against 5.0 ms untraced) is launch-bound and shows
+LESS overlap than the real one (57 % of the traced time with a single kernel in flight).  Use tools/step_phases.py for untraced timing."""
 import csv, glob, sys
 d = sys.argv[1]; first = int(sys.argv[2]) if len(sys.argv) > 2 else 8; nst = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 rows = list(csv.DictReader(open(glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0])))
