@@ -721,12 +721,12 @@ static int forward_impl(const fc_model* m, const float* params, const void* wc, 
   w.feat_out = feat_out; w.droppath = droppath; w.ids = ids;
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
   const bool both = m->tw[0].present && m->tw[1].present;
-  if (both) {   // text tower on the side stream, image tower as two micro-batch chains on two more streams
+  const int nmb = m->tw[0].present ? microbatches(m, B) : 1;
+  if (both || nmb > 1) {   // text tower on the side stream, image tower as two micro-batch chains on two more streams (also without a text tower)
     FC_TRY(fork_side(m, s));
     Ctx c2 = c;
     c2.s = m->side;
-    if (!FC_ABLATED("txt")) FC_TRY(tower_forward(c2, w, 1, nullptr, ids, feat_out, out_txt));
-    const int nmb = microbatches(m, B);
+    if (both && !FC_ABLATED("txt")) FC_TRY(tower_forward(c2, w, 1, nullptr, ids, feat_out, out_txt));
     if (nmb > 1) {
       const size_t ipx = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
       const size_t ow = (size_t)((feat_out || m->tw[0].task == FC_TASK_RTV) ? m->cfg.dim : m->tw[0].ncls);
@@ -990,12 +990,16 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     late = nullptr;       // every weight gradient is complete before the sum below
   }
   const bool run0 = m->tw[0].present && d_out_img, run1 = m->tw[1].present && d_out_txt;
-  if (run0 && run1) {
+  const int nmb = (run0 && c.defer) ? microbatches(m, w.B) : 1;
+  if (run0 && (run1 || nmb > 1)) {
+    // a classification head's weight gradients ACCUMULATE (generic GEMM, colsum): take the head of the full batch on the caller's
+    // stream before the chains fork, instead of once per chain on concurrent streams
+    const bool cls_head = !(w.feat_out || m->tw[0].task == FC_TASK_RTV);
+    if (nmb > 1 && cls_head) FC_TRY(tower_backward(c, w, 0, d_out_img, grads, PH_HEAD));
     FC_TRY(fork_side(m, s));
     Ctx c2 = c;
     c2.s = m->side;
-    if (!FC_ABLATED("txt")) FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads));   // text tower (short) first: its dW chunks start early
-    const int nmb = c.defer ? microbatches(m, w.B) : 1;
+    if (run1 && !FC_ABLATED("txt")) FC_TRY(tower_backward(c2, w, 1, d_out_txt, grads));   // text tower (short) first: its dW chunks start early
     if (nmb > 1) {
       // image tower as micro-batch chains, interleaved layer by layer; the full-batch weight gradients of a layer are
       // queued once every chain has enqueued it, and flushed to the dW stream every few layers behind ALL chains
@@ -1013,7 +1017,8 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
       }
       Ctx cf_ = c;
       cf_.n_more = nmb - 1;
-      for (int k = 0; k < nmb; ++k) FC_TRY(tower_backward(ck[k], wk[k], 0, dk[k], grads, PH_HEAD));
+      if (!cls_head)
+        for (int k = 0; k < nmb; ++k) FC_TRY(tower_backward(ck[k], wk[k], 0, dk[k], grads, PH_HEAD));
       for (int l = m->cfg.depth - 1; l >= 0; --l) {
         for (int k = 0; k < nmb; ++k) FC_TRY(tower_backward(ck[k], wk[k], 0, dk[k], grads, PH_LAYER, l));
         FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_LAYER, l));

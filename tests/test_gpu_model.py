@@ -121,9 +121,12 @@ def test_errors_are_loud():
         cpu_model([torch.zeros(2, 3, 224, 224), None])                   # no CPU fallback
 
 
-def test_microbatch_chains_do_not_change_the_result(tmp_path):
-    """The image tower runs as two micro-batch chains by default (FC_MICROBATCH, read once per process): an odd batch (B = 17 ->
-    8 + 9) gives the same gradients as the single-chain run up to the order of the LayerNorm partial sums."""
+@pytest.mark.parametrize("kind", ["img+txt", "img"])
+def test_microbatch_chains_do_not_change_the_result(tmp_path, kind):
+    """The image tower runs as two micro-batch chains by default (FC_MICROBATCH, read once per process), with or without a text tower
+    beside it: an odd batch (B = 17 -> 8 + 9) gives the same gradients as the single-chain run up to the order of the LayerNorm
+    partial sums.  'img' = an image classifier with trained re-param linears (its head's weight gradients are taken for the full
+    batch before the chains fork)."""
     import os
     import subprocess
     import sys
@@ -132,7 +135,7 @@ def test_microbatch_chains_do_not_change_the_result(tmp_path):
     for mb in ("1", "2"):
         f = str(tmp_path / f"mb{mb}.pt")
         env = dict(os.environ, FC_MICROBATCH=mb)
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mb_check.py"), "17", f], env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mb_check.py"), "17", f, kind], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         out[mb] = torch.load(f)
     for k in out["1"]:

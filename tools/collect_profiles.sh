@@ -41,6 +41,7 @@ timeout 200 python tools/retrieval_bench.py 5 2>/dev/null > "$OUT/retrieval_benc
 timeout 300 python tools/cream_bench.py 2>/dev/null > "$OUT/cream_bench.txt"
 timeout 300 python tools/loader_bench.py 1024 2>/dev/null > "$OUT/loader_bench.txt"
 timeout 300 python tools/vitb_step.py 64 50 2>/dev/null > "$OUT/vitb_step.txt"
+timeout 300 python tools/unimodal_step.py 50 2>/dev/null > "$OUT/unimodal_step.txt"
 rm -f "$OUT"/*.log
 ls -la "$OUT"
 cat "$OUT/bench_line.json"
