@@ -224,6 +224,27 @@ def test_vit_b_full_depth_bf16_layer_by_layer():
     print("ViT-B layer-by-layer worst:", worst)
 
 
+def test_vit_b_full_depth_aux_client_bf16_layer_by_layer():
+    """BASELINE.json config[3]'s uni-modal client at its stated size: ViT-B/16 image classifier, 12 layers, --aux --aux_trained
+    (re-param linears W + s*A on every linear, trained aux), B = 32 (two micro-batch chains), teacher-forced per layer against the
+    emulating oracle, aux gradients included."""
+    mk = dict(modalities=["img", None], num_classes=[100, None], tasks=["cls", None], embed_dim=768, depth=12, num_heads=12, vocab_size=30522,
+              max_text_len=40, with_aux=True, aux_trained=True)
+    sd = _default_init(mk, 13, scale=0.25)
+    B, D, H = 32, 768, 12
+    img, ids = _batch(B, 40, 30522, seed=78)
+    y = (torch.arange(B) * 7 + 1) % 100
+    model = PU.build_product(mk, "bf16", sd)
+    model.train()
+    loss, grads, _ = PU.product_step(model, "img", img, ids, y, 1e-4)
+    worst = ("", 0.0)
+    for l in (0, 6, 11):
+        w = _layer_local(model, sd, grads, B, 0, 0, 197, l, D, H, aux_trained=True, tol_1d=0.1)
+        if w[1] > worst[1]:
+            worst = w
+    print("ViT-B aux client layer-by-layer worst:", worst)
+
+
 def test_vit_s_bf16_droppath_masks_vs_emulating_oracle():
     """The bf16 drop-path epilogue (EPI_RES_SCALE) and the scaled backward, reference default --dropout 0.1 (timm DropPath,
     mome.py:213,223,726-728), with host-drawn masks handed to both sides."""
