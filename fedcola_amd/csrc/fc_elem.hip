@@ -843,6 +843,52 @@ int fc_reparam_grad(const float* gW, const float* A, const float* scale, float* 
   return 0;
 }
 
+// grouped forms: blockIdx.y = linear, blockIdx.x = slice of it (same arithmetic as the single-linear kernels above)
+#define RP_SLICES 64
+__global__ void __launch_bounds__(256) k_reparam_grad_grouped(const FcReparam* __restrict__ tab, const float* __restrict__ params, float* __restrict__ grads) {
+  __shared__ float red[4];
+  const FcReparam e = tab[blockIdx.y];
+  const float* gW = grads + e.w;
+  const float* A = params + e.aux;
+  float* gA = e.aux_trainable ? grads + e.aux : nullptr;
+  const float s = params[e.scale];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)e.n; i += (size_t)RP_SLICES * 256) {
+    const float gw = gW[i];
+    acc += gw * A[i];
+    if (gA) gA[i] += s * gw;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(grads + e.scale, red[0] + red[1] + red[2] + red[3]);
+}
+int fc_reparam_grad_grouped(const FcReparam* tab_dev, int nlin, const float* params, float* grads, hipStream_t s) {
+  if (nlin <= 0) return 0;
+  hipLaunchKernelGGL(k_reparam_grad_grouped, dim3(RP_SLICES, nlin), dim3(256), 0, s, tab_dev, params, grads);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_reparam_fold_grouped(const FcReparam* __restrict__ tab, const float* __restrict__ params, T* __restrict__ wc) {
+  const FcReparam e = tab[blockIdx.y];
+  const float* W = params + e.w;
+  const float* A = params + e.aux;
+  const float s = params[e.scale];
+  T* dst = wc + e.w;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)e.n; i += (size_t)RP_SLICES * 256) {
+#pragma clang fp contract(off)      // as k_reparam_fold: product rounded, then the sum (fedavgclient.py:176)
+    const float t = s * A[i];
+    Io<T>::st(dst, i, W[i] + t);
+  }
+}
+int fc_reparam_fold_grouped(int dt, const FcReparam* tab_dev, int nlin, const float* params, void* wc, hipStream_t s) {
+  if (nlin <= 0) return 0;
+  DISPATCH_DT(dt, hipLaunchKernelGGL(k_reparam_fold_grouped<T>, dim3(RP_SLICES, nlin), dim3(256), 0, s, tab_dev, params, (T*)wc));
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
 // ======================================================================== column sums (bias gradients)
 // grid: (ceil(N/64), row-chunks); each block sums 64 columns over its row chunk, 4 waves stride rows; atomics across chunks
 template <typename T>

@@ -92,6 +92,10 @@ int fc_cast(int dt_out, const float* src, void* dst, size_t n, hipStream_t s);
 int fc_reparam_fold(int dt, const float* W, const float* A, const float* scale, void* dst, size_t n, hipStream_t s);
 // given dW_eff in gW: ds += <gW, A>; gA = s*gW (if gA != null)
 int fc_reparam_grad(const float* gW, const float* A, const float* scale, float* ds, float* gA, size_t n, hipStream_t s);
+// every re-param linear of a model in ONE launch each (a client step otherwise spends ~100 small launches on them in its serial tail)
+struct FcReparam { int64_t w, aux, scale, n; int32_t aux_trainable, pad; };
+int fc_reparam_grad_grouped(const FcReparam* tab_dev, int nlin, const float* params, float* grads, hipStream_t s);
+int fc_reparam_fold_grouped(int dt, const FcReparam* tab_dev, int nlin, const float* params, void* wc, hipStream_t s);
 
 // ---- column sum (bias grads): db[n] (+)= sum_m dy[m,n]
 int fc_colsum(int dt, const void* dy, float* db, int M, int N, int accumulate, hipStream_t s);

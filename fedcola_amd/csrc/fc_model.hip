@@ -75,6 +75,7 @@ struct fc_model {
     if (tables_dev) (void)hipFree(tables_dev);
     if (rest_dev) (void)hipFree(rest_dev);
     if (shared_dev) (void)hipFree(shared_dev);
+    if (reparam_dev) (void)hipFree(reparam_dev);
     if (ev_dw_in) (void)hipEventDestroy(ev_dw_in);
     for (int k = 0; k < 3; ++k) {
       if (ev_dw_in2[k]) (void)hipEventDestroy(ev_dw_in2[k]);
@@ -95,6 +96,9 @@ struct fc_model {
   int64_t shared_lo = 0, shared_hi = 0;
   std::vector<FcProxChunk> shared_chunks;
   mutable void* shared_dev = nullptr;
+  // re-param linears: device table for the grouped fold / gradient-routing launches (rebuilt when a trainable flag changes)
+  mutable std::vector<FcReparam> reparam_host;
+  mutable void* reparam_dev = nullptr;
   int dt;  // FC_F32 / FC_BF16 activation + compute-weight type
   bool need_wc;
   int64_t add(const std::string& name, std::vector<int64_t> shape, int trainable = 1) {
@@ -413,16 +417,34 @@ static int for_each_linear(const fc_model* m, F f) {
   return 0;
 }
 
+// device table of the re-param linears (cached in the handle; a changed trainable flag rebuilds it: one device synchronisation)
+static int reparam_table(const fc_model* m, const FcReparam** tab, int* n) {
+  std::vector<FcReparam> t;
+  (void)for_each_linear(m, [&](const LinearP& L) -> int {
+    if (L.aux >= 0) t.push_back(FcReparam{L.w, L.aux, L.scale, (int64_t)L.out * L.in, m->segs[L.seg_w + 3].trainable ? 1 : 0, 0});
+    return 0;
+  });
+  *n = (int)t.size();
+  *tab = nullptr;
+  if (t.empty()) return 0;
+  if (!m->reparam_dev || m->reparam_host.size() != t.size() || memcmp(m->reparam_host.data(), t.data(), t.size() * sizeof(FcReparam)) != 0) {
+    FC_CHECK_HIP(hipDeviceSynchronize());
+    if (m->reparam_dev) FC_CHECK_HIP(hipFree(m->reparam_dev));
+    FC_CHECK_HIP(hipMalloc(&m->reparam_dev, t.size() * sizeof(FcReparam)));
+    FC_CHECK_HIP(hipMemcpy(m->reparam_dev, t.data(), t.size() * sizeof(FcReparam), hipMemcpyHostToDevice));
+    m->reparam_host = t;
+  }
+  *tab = (const FcReparam*)m->reparam_dev;
+  return 0;
+}
 extern "C" int fc_prepare_weights(const fc_model_t* m, const float* params, void* wc, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!m->need_wc) return 0;
   FC_REQUIRE(wc && wc != (const void*)params, "fc_prepare_weights: a separate compute-weight buffer is required");
   FC_TRY(fc_cast(m->dt, params, wc, (size_t)m->total, s));
-  size_t es = fc_esize(m->dt);
-  return for_each_linear(m, [&](const LinearP& L) -> int {
-    if (L.aux < 0) return 0;
-    return fc_reparam_fold(m->dt, params + L.w, params + L.aux, params + L.scale, (char*)wc + (size_t)L.w * es, (size_t)L.out * L.in, s);
-  });
+  const FcReparam* tab; int n;
+  FC_TRY(reparam_table(m, &tab, &n));
+  return fc_reparam_fold_grouped(m->dt, tab, n, params, wc, s);      // W + s*A of every re-param linear in one launch
 }
 
 extern "C" int fc_upload_fold(const fc_model_t* m, const float* params, float* dst, void* stream) {
@@ -937,19 +959,11 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
 
 // CrossModalReparamLinear: route dW_eff (mome.py:58-60).  Runs after the weight gradients exist (i.e. after the grouped launch).
 static int tower_reparam_grads(const Ctx& c, int i, float* grads) {
-  const fc_model* m = c.m;
-  const TowerP& tp = m->tw[i];
-  const float* P = c.params;
-  // CrossModalReparamLinear: route dW_eff (mome.py:58-60)
-  for (const BlockP& b : tp.blocks) {
-    const LinearP* Ls[4] = {&b.qkv, &b.proj, &b.fc1, &b.fc2};
-    for (const LinearP* L : Ls) {
-      if (L->aux < 0) continue;
-      float* gA = m->segs[L->seg_w + 3].trainable ? grads + L->aux : nullptr;
-      FC_TRY(fc_reparam_grad(grads + L->w, P + L->aux, P + L->scale, grads + L->scale, gA, (size_t)L->out * L->in, c.s));
-    }
-  }
-  return 0;
+  // CrossModalReparamLinear: route dW_eff (mome.py:58-60) -- every re-param linear of the model in one launch (re-param models are
+  // uni-modal, mome.py:768: the call for the one present tower covers them all)
+  const FcReparam* tab; int n;
+  FC_TRY(reparam_table(c.m, &tab, &n));
+  return fc_reparam_grad_grouped(tab, n, c.params, grads, c.s);
 }
 
 // The LAST weight-gradient chunk (the lowest layers of the image tower + the patch embedding) starts when the whole backward is done and
