@@ -792,6 +792,16 @@ static int dw_flush_every() {
 // flush after layer l?  (phase 1 would make the last, un-overlapped chunk the smallest -- layer 0 + embedding -- but
 // measured 2 % slower than phase 0 on the ViT-S step)
 static bool dw_flush_here(int l) {
+  // FC_DW_FLUSH_AT="6,1": explicit list of layers after which the queued weight gradients are launched (experiments)
+  static const char* at = getenv("FC_DW_FLUSH_AT");
+  if (at) {
+    for (const char* p = at; *p;) {
+      if (atoi(p) == l && l > 0) return true;
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+    return false;
+  }
   static int ph = getenv("FC_DW_PHASE") ? atoi(getenv("FC_DW_PHASE")) : 0;
   const int e = dw_flush_every();
   return l > 0 && (l % e) == (ph % e);
