@@ -51,201 +51,8 @@ template <> struct V8<bf16_t> {
     *(uint4*)p = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
   }
 };
-#define LNV_MAXC 2  // chunks of 8 per lane: D <= 64*8*2
-
-template <typename T>
-__global__ void __launch_bounds__(256) k_ln_fwd_v(const T* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                                  T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const int nc = D >> 3;
-  float v[LNV_MAXC][8];
-  float s = 0.f;
-#pragma unroll
-  for (int t = 0; t < LNV_MAXC; ++t) {
-    int c = lane + 64 * t;
-    if (c < nc) {
-      V8<T>::ld(x + (size_t)row * D + c * 8, v[t]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += v[t][i];
-    }
-  }
-  float mu = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int t = 0; t < LNV_MAXC; ++t)
-    if (lane + 64 * t < nc) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { float d = v[t][i] - mu; q += d * d; }
-    }
-  float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-#pragma unroll
-  for (int t = 0; t < LNV_MAXC; ++t) {
-    int c = lane + 64 * t;
-    if (c < nc) {
-      float gg[8], bb[8], o[8];
-      V8<float>::ld(g + c * 8, gg);
-      V8<float>::ld(b + c * 8, bb);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = (v[t][i] - mu) * rs * gg[i] + bb[i];
-      V8<T>::st(y + (size_t)row * D + c * 8, o);
-    }
-  }
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-}
-
-// Backward: a block = 16 rows, a wave owns 4 CONSECUTIVE rows and handles them together: the 12 row loads (dy, x, res of four
-// rows) are in flight at once and the eight wave reductions are interleaved, so a wave pays one memory round trip instead of four
-// dependent ones (measured at M = 12 608, D = 384: 27 us -> see profiles/r02).  dgamma / dbeta: per-lane column sums over the
-// wave's rows, combined across the 4 waves in LDS, one partial row per block (or atomics without `partial`).
-#define LNB_R 4
-#ifdef FC_PROBES
-__device__ long long g_ln_stamps[1024 * 8];     // tools build: s_memrealtime stamps of wave 0 of each block (10 ns units)
-#define LN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ln_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-extern "C" int fc_dbg_ln_read_stamps(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ln_stamps), sizeof(long long) * 1024 * 8); }
-#else
-#define LN_STAMP(i) do {} while (0)
-#endif
-template <typename T, int CH>      // CH: 8-column chunks per lane (1: D <= 512)
-__global__ void __launch_bounds__(256) k_ln_bwd_v(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
-                                                  const float* __restrict__ rstd, const float* __restrict__ g, const T* res, T* dx,
-                                                  float* __restrict__ dg, float* __restrict__ db, int M, int D, int rows_per_block,
-                                                  float* __restrict__ partial, T* dx_scaled, const float* __restrict__ rowscale, int rows_per_sample) {
-  extern __shared__ float red_dyn[];   // [2][4][D]: sized by the launch, so that narrow models keep many blocks per CU
-#define RED(a, w, i) red_dyn[((a) * 4 + (w)) * D + (i)]
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nc = D >> 3;
-  LN_STAMP(0);
-  float ag[CH][8], ab[CH][8], gg[CH][8];
-#pragma unroll
-  for (int t = 0; t < CH; ++t) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { ag[t][i] = 0.f; ab[t][i] = 0.f; gg[t][i] = 0.f; }
-    if (lane + 64 * t < nc) V8<float>::ld(g + (lane + 64 * t) * 8, gg[t]);
-  }
-  const int row0 = blockIdx.x * rows_per_block;
-  const int per_wave = rows_per_block / 4;                  // consecutive rows of this wave
-  for (int rb = 0; rb < per_wave; rb += LNB_R) {
-    float d[LNB_R][CH][8], xh[LNB_R][CH][8], rr[LNB_R][CH][8];
-    float mu[LNB_R], rs[LNB_R], s1[LNB_R], s2[LNB_R];
-    int row[LNB_R];
-#pragma unroll
-    for (int q = 0; q < LNB_R; ++q) {                       // every load of the four rows first
-      row[q] = row0 + wave * per_wave + rb + q;
-      const int rc = row[q] < M ? row[q] : M - 1;
-      mu[q] = mean[rc]; rs[q] = rstd[rc];
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        const int c = lane + 64 * t;
-        if (c < nc) {
-          V8<T>::ld(dy + (size_t)rc * D + c * 8, d[q][t]);
-          V8<T>::ld(x + (size_t)rc * D + c * 8, xh[q][t]);
-          if (res) V8<T>::ld(res + (size_t)rc * D + c * 8, rr[q][t]);
-        }
-      }
-    }
-    LN_STAMP(1);
-#pragma unroll
-    for (int q = 0; q < LNB_R; ++q) {
-      s1[q] = 0.f; s2[q] = 0.f;
-      const bool live = row[q] < M;
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        if (lane + 64 * t < nc) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            xh[q][t][i] = (xh[q][t][i] - mu[q]) * rs[q];
-            const float dxh = d[q][t][i] * gg[t][i];
-            s1[q] += dxh; s2[q] += dxh * xh[q][t][i];
-            if (live) { ag[t][i] += d[q][t][i] * xh[q][t][i]; ab[t][i] += d[q][t][i]; }
-          }
-        }
-      }
-    }
-    LN_STAMP(2);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {                      // the eight reductions side by side
-#pragma unroll
-      for (int q = 0; q < LNB_R; ++q) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
-    }
-    LN_STAMP(3);
-#pragma unroll
-    for (int q = 0; q < LNB_R; ++q) {
-      if (row[q] >= M) continue;
-      const float m1 = s1[q] / (float)D, m2 = s2[q] / (float)D;
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        const int c = lane + 64 * t;
-        if (c < nc) {
-          float o[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = rs[q] * (d[q][t][i] * gg[t][i] - m1 - xh[q][t][i] * m2) + (res ? rr[q][t][i] : 0.f);
-          V8<T>::st(dx + (size_t)row[q] * D + c * 8, o);
-          if (dx_scaled) {      // drop-path: the consumer of this gradient wants it times the per-sample multiplier (of the STORED value)
-            const float sc = rowscale[row[q] / rows_per_sample];
-            float os[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) os[i] = Io<T>::rt(o[i]) * sc;
-            V8<T>::st(dx_scaled + (size_t)row[q] * D + c * 8, os);
-          }
-        }
-      }
-    }
-  }
-  LN_STAMP(4);
-#pragma unroll
-  for (int t = 0; t < CH; ++t) {
-    int c = lane + 64 * t;
-    if (c < nc) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { RED(0, wave, c * 8 + i) = ag[t][i]; RED(1, wave, c * 8 + i) = ab[t][i]; }
-    }
-  }
-  __syncthreads();
-  LN_STAMP(5);
-  if (partial) {  // [block][dg(D) | db(D)], reduced later by k_ln_reduce_grouped (no same-address atomic storm)
-    float* pp = partial + (size_t)blockIdx.x * 2 * D;
-    for (int i = threadIdx.x; i < D; i += 256) {
-      pp[i] = RED(0, 0, i) + RED(0, 1, i) + RED(0, 2, i) + RED(0, 3, i);
-      pp[D + i] = RED(1, 0, i) + RED(1, 1, i) + RED(1, 2, i) + RED(1, 3, i);
-    }
-    LN_STAMP(6);
-    return;
-  }
-  for (int i = threadIdx.x; i < D; i += 256) {
-    atomicAdd(dg + i, RED(0, 0, i) + RED(0, 1, i) + RED(0, 2, i) + RED(0, 3, i));
-    atomicAdd(db + i, RED(1, 0, i) + RED(1, 1, i) + RED(1, 2, i) + RED(1, 3, i));
-  }
-#undef RED
-}
-
-// grouped reduction of the LayerNorm-backward partials: block (x = column chunk of 64, y = LN instance, z = slice of the
-// partial rows); the slices meet in the final atomic add (the gradient buffer is zeroed at the start of the step)
-#define LNR_SLICES 8
-__global__ void __launch_bounds__(256) k_ln_reduce_grouped(const FcLnReduce* __restrict__ tab) {
-  __shared__ float red[4][64];
-  const FcLnReduce e = tab[blockIdx.y];
-  int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
-  int W = 2 * e.D;
-  float acc = 0.f;
-  if (col < W)
-    for (int bk = blockIdx.z * 4 + wave; bk < e.nblocks; bk += 4 * LNR_SLICES) acc += e.partial[(size_t)bk * W + col];
-  red[wave][threadIdx.x & 63] = acc;
-  __syncthreads();
-  if (wave == 0 && col < W) {
-    float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (col < e.D) atomicAdd(e.dg + col, v); else atomicAdd(e.db + col - e.D, v);
-  }
-}
-int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s) {
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_ln_reduce_grouped, dim3(fc_cdiv(2 * maxD, 64), n, LNR_SLICES), dim3(256), 0, s, tab_dev);
-  FC_LAUNCH_CHECK();
-  return 0;
-}
-
 static bool ln_vec_ok(const void* a, const void* b, const void* c, const void* d, int D) {
-  return (D % 8 == 0) && D <= 64 * 8 * LNV_MAXC && !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15);
+  return fc_layernorm_grouped_ok(D) && !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15);
 }
 
 int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int D,
@@ -253,9 +60,10 @@ int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void
   if (FC_ABLATED("ln")) return 0;
   if (M <= 0) return 0;
   if (ln_vec_ok(x, y, g, b, D)) {
-    DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_fwd_v<T>, dim3(fc_cdiv(M, 4)), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, M, D, eps));
-    FC_LAUNCH_CHECK();
-    return 0;
+    FcLnFwdArgs a{};
+    a.p[0] = FcLnFwdP{x, y, g, b, mean, rstd, M, 0};
+    a.nprob = 1; a.D = D; a.eps = eps;
+    return fc_layernorm_fwd_grouped(dt, a, s);
   }
   DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_fwd<T>, dim3(fc_cdiv(M, 4)), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, M, D, eps));
   FC_LAUNCH_CHECK();
@@ -320,7 +128,6 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const T* __restrict__ dy, const 
   }
 }
 
-int fc_layernorm_bwd_partial_blocks(int M) { return fc_cdiv(M, 16); }
 
 // plain per-row scaled copy (drop-path backward where no LayerNorm backward produces the operand): 16-byte accesses when possible
 template <typename T>
@@ -361,17 +168,12 @@ int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, c
                      int rows_per_sample) {
   if (FC_ABLATED("ln")) return 0;
   if (M <= 0) return 0;
-  if (ln_vec_ok(dy, x, dx, res, D) && !((uintptr_t)g & 15)) {
-    const int rpb = 16;
-    if (D <= 512) {
-      DISPATCH_DT(dt, hipLaunchKernelGGL((k_ln_bwd_v<T, 1>), dim3(fc_cdiv(M, rpb)), dim3(256), sizeof(float) * 8 * D, s, (const T*)dy, (const T*)x, mean,
-                                         rstd, g, (const T*)res, (T*)dx, dg, db, M, D, rpb, partial, (T*)dx_scaled, rowscale, rows_per_sample));
-    } else {
-      DISPATCH_DT(dt, hipLaunchKernelGGL((k_ln_bwd_v<T, LNV_MAXC>), dim3(fc_cdiv(M, rpb)), dim3(256), sizeof(float) * 8 * D, s, (const T*)dy, (const T*)x,
-                                         mean, rstd, g, (const T*)res, (T*)dx, dg, db, M, D, rpb, partial, (T*)dx_scaled, rowscale, rows_per_sample));
-    }
-    FC_LAUNCH_CHECK();
-    return partial ? 1 : 0;   // 1: dg/db are pending in `partial` (caller queues the grouped reduction)
+  if (partial && ln_vec_ok(dy, x, dx, res, D) && !(((uintptr_t)g | (uintptr_t)partial | (uintptr_t)dx_scaled) & 15)) {
+    FcLnBwdArgs a{};
+    a.p[0] = FcLnBwdP{dy, x, mean, rstd, g, res, dx, dx_scaled, rowscale, partial, rows_per_sample, M, 0, 0};
+    a.nprob = 1; a.D = D;
+    FC_TRY(fc_layernorm_bwd_grouped(dt, a, s));
+    return 1;   // dg/db are pending in `partial` (caller queues the grouped reduction)
   }
   FC_REQUIRE(D <= 64 * LNB_MAXV, "layernorm_bwd: D=%d > %d unsupported", D, 64 * LNB_MAXV);
   DISPATCH_DT(dt, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(fc_cdiv(M, LNB_ROWS)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, g,
@@ -529,9 +331,101 @@ __global__ void __launch_bounds__(256) k_txt_embed_bwd(const T* __restrict__ dy,
     atomicAdd(db + i, red[2][0][i] + red[2][1][i] + red[2][2][i] + red[2][3][i]);
   }
 }
+// 16-byte vector form (D % 8 == 0, D <= 1024): block = (token position n, 16 samples), 16 lanes per row as in fc_ln.hip, so that B x N
+// rows spread over N x B/16 blocks (the one-block-per-position form above runs on 32 of 256 CUs at N = 32: 139 us at B = 64).
+// dpos[n] / dtype / dgamma / dbeta: summed over the block's rows in registers and LDS, one atomic per column per block.
+template <typename T, int CH>
+__global__ void __launch_bounds__(256) k_txt_embed_bwd_v(const T* __restrict__ dy, const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                         const float* __restrict__ pos, const float* __restrict__ type,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ g, float* dword, float* dpos, float* dtype, float* dg,
+                                                         float* db, int B, int N, int D, int vocab) {
+  extern __shared__ float red_dyn[];   // [4 waves][3][D]
+  const int n = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 15, slot = lane >> 4;
+  const int nc = D >> 3;
+  const int bi = blockIdx.y * 16 + wave * 4 + slot;
+  const bool live = bi < B;
+  const int row = (live ? bi : B - 1) * N + n;
+  const long id = clamp_id(ids[row], vocab);
+  const float mu = mean[row], rs = rstd[row];
+  float d[CH][8], xh[CH][8], gg[CH][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = sub + 16 * t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d[t][i] = 0.f; xh[t][i] = 0.f; gg[t][i] = 0.f; }
+    if (c < nc) {
+      float w[8], ty[8], pp[8];
+      V8<T>::ld(dy + (size_t)row * D + c * 8, d[t]);
+      V8<float>::ld(word + (size_t)id * D + c * 8, w);
+      V8<float>::ld(type + c * 8, ty);
+      V8<float>::ld(pos + (size_t)n * D + c * 8, pp);
+      V8<float>::ld(g + c * 8, gg[t]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xh[t][i] = (w[i] + ty[i] + pp[i] - mu) * rs;
+        s1 += d[t][i] * gg[t][i]; s2 += d[t][i] * gg[t][i] * xh[t][i];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  s1 /= (float)D; s2 /= (float)D;
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = sub + 16 * t;
+    float de[8], gm[8], bt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      de[i] = live ? rs * (d[t][i] * gg[t][i] - s1 - xh[t][i] * s2) : 0.f;
+      gm[i] = live ? d[t][i] * xh[t][i] : 0.f;
+      bt[i] = live ? d[t][i] : 0.f;
+    }
+    if (c < nc && live && id != 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(dword + (size_t)id * D + c * 8 + i, de[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {    // the wave's four rows
+      de[i] += __shfl_xor(de[i], 16, 64); de[i] += __shfl_xor(de[i], 32, 64);
+      gm[i] += __shfl_xor(gm[i], 16, 64); gm[i] += __shfl_xor(gm[i], 32, 64);
+      bt[i] += __shfl_xor(bt[i], 16, 64); bt[i] += __shfl_xor(bt[i], 32, 64);
+    }
+    if (slot == 0 && c < nc) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        red_dyn[(wave * 3 + 0) * D + c * 8 + i] = de[i];
+        red_dyn[(wave * 3 + 1) * D + c * 8 + i] = gm[i];
+        red_dyn[(wave * 3 + 2) * D + c * 8 + i] = bt[i];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float de = red_dyn[(0 * 3 + 0) * D + i] + red_dyn[(1 * 3 + 0) * D + i] + red_dyn[(2 * 3 + 0) * D + i] + red_dyn[(3 * 3 + 0) * D + i];
+    atomicAdd(dpos + (size_t)n * D + i, de);
+    atomicAdd(dtype + i, de);
+    atomicAdd(dg + i, red_dyn[(0 * 3 + 1) * D + i] + red_dyn[(1 * 3 + 1) * D + i] + red_dyn[(2 * 3 + 1) * D + i] + red_dyn[(3 * 3 + 1) * D + i]);
+    atomicAdd(db + i, red_dyn[(0 * 3 + 2) * D + i] + red_dyn[(1 * 3 + 2) * D + i] + red_dyn[(2 * 3 + 2) * D + i] + red_dyn[(3 * 3 + 2) * D + i]);
+  }
+}
 int fc_txt_embed_bwd(int dt, const void* dy, const int64_t* ids, const float* word, const float* pos, const float* type, const float* mean,
                      const float* rstd, const float* g, float* dword, float* dpos, float* dtype, float* dg, float* db, int B, int N, int D,
                      int vocab, hipStream_t s) {
+  if ((D & 7) == 0 && D <= 1024 && !(((uintptr_t)dy | (uintptr_t)word | (uintptr_t)pos | (uintptr_t)type | (uintptr_t)g) & 15)) {
+    const int ch = fc_cdiv(D / 8, 16);
+    const size_t lds = sizeof(float) * 12 * D;
+#define GO(CHN) DISPATCH_DT(dt, hipLaunchKernelGGL((k_txt_embed_bwd_v<T, CHN>), dim3(N, fc_cdiv(B, 16)), dim3(256), lds, s, (const T*)dy, ids, word, pos, type, \
+                                                   mean, rstd, g, dword, dpos, dtype, dg, db, B, N, D, vocab))
+    switch (ch) {
+      case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
+      case 5: case 6: GO(6); break; default: GO(8); break;
+    }
+#undef GO
+    FC_LAUNCH_CHECK();
+    return 0;
+  }
   FC_REQUIRE(D <= 64 * TEB_MAXV, "txt_embed_bwd: D=%d > %d unsupported", D, 64 * TEB_MAXV);
   DISPATCH_DT(dt, hipLaunchKernelGGL(k_txt_embed_bwd<T>, dim3(N), dim3(256), 0, s, (const T*)dy, ids, word, pos, type, mean, rstd, g, dword,
                                      dpos, dtype, dg, db, B, N, D, vocab));

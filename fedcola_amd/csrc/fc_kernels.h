@@ -11,25 +11,40 @@ static inline size_t fc_esize(int dt) { return dt == FC_BF16 ? 2 : 4; }
   else { typedef bf16_t T; __VA_ARGS__; }
 
 // ---- layer norm (K3)
-int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
-                     int M, int D, float eps, hipStream_t s);
-// dx = (res ? res : 0) + LNbwd(dy); dg/db accumulated (atomics) into fp32 grads.  With `partial` (room for
-// fc_layernorm_bwd_partial_blocks(M)*2*D floats) the vector kernel writes per-block partial sums there instead and the
-// call returns 1: the caller must then run fc_ln_reduce_grouped over its queued FcLnReduce entries.
+// Grouped forms (fc_ln.hip): up to two row sets -- the image and the text tower of one layer -- in ONE launch.  D % 8 == 0, D <= 1024,
+// 16-byte aligned operands.  blk0 is filled in by the launcher.
+struct FcLnFwdP { const void* x; void* y; const float* g; const float* b; float* mean; float* rstd; int M; int blk0; };
+struct FcLnFwdArgs { FcLnFwdP p[2]; int nprob; int D; float eps; };
+// dx = (res ? res : 0) + LNbwd(dy); dx_scaled (optional): a second output dx * rowscale[row / rows_per_sample] (drop-path: the next
+// consumer's operand); partial: room for fc_layernorm_bwd_partial_blocks(M) * 2 * D floats, one [dgamma | dbeta] row per block, summed
+// later by fc_ln_reduce_grouped over the queued FcLnReduce entries
+struct FcLnBwdP {
+  const void* dy; const void* x; const float* mean; const float* rstd; const float* g; const void* res; void* dx; void* dx_scaled;
+  const float* rowscale; float* partial; int rows_per_sample; int M; int blk0; int pad;
+};
+struct FcLnBwdArgs { FcLnBwdP p[2]; int nprob; int D; };
+int fc_layernorm_grouped_ok(int D);
+int fc_layernorm_fwd_grouped(int dt, FcLnFwdArgs a, hipStream_t s);
+int fc_layernorm_bwd_grouped(int dt, FcLnBwdArgs a, hipStream_t s);
+// dgamma / dbeta = column sums of the partial rows (of up to two partial sets: two micro-batch chains); accumulate = 0: plain store (the
+// gradient buffer need not be zeroed), 1: added to the existing value.  No atomics: two entries must not name the same dg / db.
 struct FcLnReduce {
   const float* partial;
+  const float* partial2;
   float* dg;
   float* db;
-  int nblocks, D;
+  int nblocks, nblocks2, D, accumulate;
 };
 int fc_layernorm_bwd_partial_blocks(int M);
-// dx_scaled (optional): a second output dx * rowscale[row / rows_per_sample] (drop-path: the next consumer's operand), written by the
-// same pass instead of a separate scaled copy
+int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s);
+// single-row-set forms.  fc_layernorm_bwd without `partial` accumulates dg / db with atomics (scalar kernel: tests and odd shapes); with
+// `partial` it returns 1 and the caller must run fc_ln_reduce_grouped over its queued entries.
+int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
+                     int M, int D, float eps, hipStream_t s);
 int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
                      const void* res, void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial = nullptr,
                      void* dx_scaled = nullptr, const float* rowscale = nullptr, int rows_per_sample = 1);
 int fc_rowscale(int dt, const void* src, void* dst, const float* rs, int rows_per_sample, int M, int D, hipStream_t s);
-int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s);
 
 // ---- image embedding (K1): patches[B*np, C*P*P] (conv-weight order), cls rows, and backward pieces
 int fc_patchify(int dt, const float* img, void* patches, int B, int C, int HW, int P, hipStream_t s);
@@ -125,6 +140,30 @@ int fc_gemm_generic(int dtA, int dtB, int dtC, const void* A, long sam, long sak
 enum { FC_GEMM_NT = 0, FC_GEMM_NN = 1, FC_GEMM_TN = 2 };
 int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K,
                  const GemmEpi& epi, hipStream_t s);
+// the same kernel over one or two problems that share N, K and the epilogue kind (image + text tower of a layer in one launch);
+// returns 1 when not covered: the caller then launches the problems one by one
+struct GemmProb { const bf16_t* A; const bf16_t* B; void* C; long lda, ldb, ldc; int M; GemmEpi e; };
+struct GemmGroup { GemmProb p[2]; int N, K, tiles_n, tiles0, ntiles; };
+int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t s);
+
+// ---- large-tile grouped NT GEMM (fc_gemm_big.hip): C_p[M_p,N] = A_p[M_p,K] . W_p[N,K]^T for up to two row sets in one launch
+struct FcGemmProb {
+  const bf16_t* A; const bf16_t* W; bf16_t* C;
+  const float* bias;        // [N]
+  const void* res;          // residual [M, ldc] (bf16)
+  void* preact;             // GELU_SG: gelu'(acc + bias) goes here, gelu(acc + bias) to C
+  const void* mul_in;       // MUL: C = acc * mul_in
+  const float* rowscale;    // RES_SCALE: per-sample multiplier of (acc + bias) before the residual add
+  long lda, ldw, ldc;
+  int M, rows_per_sample;
+};
+struct FcGemmGrouped { FcGemmProb p[2]; int nprob, N, K, epi; };
+int fc_gemm_grouped_epi(const GemmEpi& e);   // epilogue code of this kernel for a GemmEpi (-1: not covered)
+// returns 1 when the shapes are not covered (K % 64, N % 8, alignment); force_bm: 0 = heuristic, 128 / 256 = tile rows
+int fc_gemm_nt_grouped(const FcGemmGrouped& g, hipStream_t s, int force_bm = 0);
+// transposed bf16 copies of the linears' compute weights (dst[in][out] = src[out][in]) for the dX products
+struct FcTranspose { int64_t src, dst; int32_t out, in; };
+int fc_transpose_linears(const FcTranspose* tab_dev, int n, const bf16_t* src, bf16_t* dst, hipStream_t s);
 
 // weight-stationary form for K <= 384 (fc_gemm_ws.hip); returns 1 when the shape / epilogue is not covered
 int fc_gemm_ws(int kind, const bf16_t* A, long lda, const bf16_t* W, long ldw, bf16_t* C, long ldc, int M, int N, int K, const GemmEpi& epi,

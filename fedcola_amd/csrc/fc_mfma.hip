@@ -406,31 +406,44 @@ __device__ __forceinline__ void gemm_mainloop(const bf16_t* __restrict__ A, long
 }
 
 
-// Persistent single-problem kernel: the grid is at most 2 workgroups per CU and every workgroup walks the tiles
-// id, id + grid, id + 2*grid, ...  Operand tiles stream global -> LDS directly (LDS-DMA), double-buffered: the loads of
-// k-tile t+1 (or of the NEXT output tile's first k-tile) are in flight while k-tile t feeds the MFMAs and while the
-// epilogue runs.  One barrier per k-tile: wait for own DMA (vmcnt) -> barrier -> issue next DMA -> compute.
+// Persistent kernel over the tiles of ONE or TWO problems that share N, K and the epilogue kind (the image and the text tower of a
+// layer: one launch instead of three, one read of each weight matrix, 345 instead of 150 tiles for the N = 384 shapes): the grid is
+// at most 2 workgroups per CU and every workgroup walks the tiles id, id + grid, id + 2*grid, ... of the concatenated tile list.
+// Operand tiles stream global -> LDS directly (LDS-DMA), double-buffered: the loads of k-tile t+1 (or of the NEXT output tile's
+// first k-tile) are in flight while k-tile t feeds the MFMAs and while the epilogue runs.  One barrier per k-tile: wait for own DMA
+// (vmcnt) -> barrier -> issue next DMA -> compute.
 template <int AMODE, int BMODE, typename TC, int EPI>
-__global__ void __launch_bounds__(256, 2)
-k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bm, long ldb, TC* C, long ldc, int M, int N, int K, int tiles_n,
-            int ntiles, GemmEpi e) {
+__global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A 16 KB | B 16 KB) + a separate epilogue image
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int G = gridDim.x;
   const int first = xcd_remap(blockIdx.x, G);
+  const int N = g.N, K = g.K, tiles_n = g.tiles_n, ntiles = g.ntiles;
   const int T = (K + BK - 1) / BK;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // load side: tile `lt`, k-tile `lk`, destination buffer parity `lb`
-  int lt = first, lk = 0, lb = 0;
-  Operand oa = make_operand_glds<AMODE>(A, lda, 0, M, K, wave, lane);
-  Operand ob = make_operand_glds<BMODE>(Bm, ldb, 0, N, K, wave, lane);
-  retarget_glds<AMODE>(oa, lda, (lt / tiles_n) * BM, M, wave, lane, lt < ntiles);
-  retarget_glds<BMODE>(ob, ldb, (lt % tiles_n) * BN, N, wave, lane, lt < ntiles);
+  // load side: tile `lt` (of problem `lprob`), k-tile `lk`, destination buffer parity `lb`
+  int lt = first, lk = 0, lb = 0, lprob = -1;
+  Operand oa, ob;
+  auto retarget = [&]() {
+    const bool valid = lt < ntiles;
+    const int t = valid ? lt : first;
+    const int pr = t >= g.tiles0;
+    const GemmProb& P = g.p[pr];
+    if (pr != lprob) {
+      oa = make_operand_glds<AMODE>(P.A, P.lda, 0, P.M, K, wave, lane);
+      ob = make_operand_glds<BMODE>(P.B, P.ldb, 0, N, K, wave, lane);
+      lprob = pr;
+    }
+    const int l = t - (pr ? g.tiles0 : 0);
+    retarget_glds<AMODE>(oa, P.lda, (l / tiles_n) * BM, P.M, wave, lane, valid);
+    retarget_glds<BMODE>(ob, P.ldb, (l % tiles_n) * BN, N, wave, lane, valid);
+  };
+  retarget();
 #define ISSUE_NEXT()                                                                   \
   do {                                                                                 \
     char* dst = smem + lb * 32768;                                                     \
@@ -440,19 +453,22 @@ k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B
     if (++lk == T) {                                                                   \
       lk = 0;                                                                          \
       lt += G;                                                                         \
-      retarget_glds<AMODE>(oa, lda, (lt / tiles_n) * BM, M, wave, lane, lt < ntiles);  \
-      retarget_glds<BMODE>(ob, ldb, (lt % tiles_n) * BN, N, wave, lane, lt < ntiles);  \
+      retarget();                                                                      \
     }                                                                                  \
   } while (0)
   ISSUE_NEXT();                      // k-tile 0 of the first tile -> buffer 0
   int cb = 0;                        // buffer holding the k-tile to compute next
-  const long crows = (long)M + (e.patch_rows > 0 ? M / e.patch_rows + 2 : 0);
-  const __amdgpu_buffer_rsrc_t crs = make_store_rsrc((void*)C, crows * ldc * (long)sizeof(TC));
-  const __amdgpu_buffer_rsrc_t prs = make_store_rsrc(e.preact ? e.preact : (void*)C, crows * ldc * (long)sizeof(TC));
   constexpr int NST = EpiStores<EPI, TC>::n;
   EpiRegs pre;
   for (int ct = first; ct < ntiles; ct += G) {
-    const int m0 = (ct / tiles_n) * BM, n0 = (ct % tiles_n) * BN;
+    const int pr = ct >= g.tiles0;
+    const GemmProb& P = g.p[pr];
+    const GemmEpi& e = P.e;
+    const int M = P.M;
+    const long ldc = P.ldc;
+    TC* C = (TC*)P.C;
+    const int lct = ct - (pr ? g.tiles0 : 0);
+    const int m0 = (lct / tiles_n) * BM, n0 = (lct % tiles_n) * BN;
     for (int k = 0; k < T; ++k) {
       // this wave's pieces of the current k-tile have landed.  Right after an epilogue the youngest NST operations are that
       // epilogue's stores (a fixed count per thread): skip them instead of draining the HBM write latency.
@@ -467,6 +483,9 @@ k_gemm_mfma(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B
     }
     // ---- epilogue, two 64-row halves through the staging buffer that was computed last (the other one is receiving the
     // next tile's first k-tile by DMA meanwhile)
+    const long crows = (long)M + (e.patch_rows > 0 ? M / e.patch_rows + 2 : 0);
+    const __amdgpu_buffer_rsrc_t crs = make_store_rsrc((void*)C, crows * ldc * (long)sizeof(TC));
+    const __amdgpu_buffer_rsrc_t prs = make_store_rsrc(e.preact ? e.preact : (void*)C, crows * ldc * (long)sizeof(TC));
     float* Cs = (float*)(smem + (cb ^ 1) * 32768);
     lds_barrier();                                         // last MFMA fragment reads of this buffer are done
     acc_to_lds_half<0>(Cs, acc, wm, wn, lane);
@@ -612,8 +631,7 @@ int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles,
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int AM, int BMo, typename TC, int EPI>
-static int launch_gemm_epi(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K, int tiles_n,
-                           const GemmEpi& epi, hipStream_t s) {
+static int launch_gemm_epi(const GemmGroup& g, hipStream_t s) {
   const int lds = 65536;  // two 32-KB staging buffers; the epilogue image aliases the idle one
   auto kfn = k_gemm_mfma<AM, BMo, TC, EPI>;
   static bool attr_done = false;  // one flag per instantiation
@@ -628,8 +646,8 @@ static int launch_gemm_epi(int tiles, const bf16_t* A, long lda, const bf16_t* B
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     max_wg = 2 * cus;   // 64 KB of LDS per workgroup: two per CU
   }
-  int grid = tiles < max_wg ? tiles : max_wg;
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, A, lda, Bm, ldb, (TC*)C, ldc, M, N, K, tiles_n, tiles, epi);
+  int grid = g.ntiles < max_wg ? g.ntiles : max_wg;
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, g);
   FC_LAUNCH_CHECK();
   return 0;
 }
@@ -646,10 +664,8 @@ static int epi_kind(const GemmEpi& e) {
 }
 // the epilogue kinds each GEMM form is instantiated for (anything else takes the run-time-flag EPI_GENERIC body)
 template <int AM, int BMo, typename TC>
-static int launch_gemm(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K, int tiles_n,
-                       const GemmEpi& epi, hipStream_t s) {
-#define GO(E) return launch_gemm_epi<AM, BMo, TC, E>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s)
-  const int k = epi_kind(epi);
+static int launch_gemm(const GemmGroup& g, int k, hipStream_t s) {
+#define GO(E) return launch_gemm_epi<AM, BMo, TC, E>(g, s)
   if (AM == KC && BMo == KC && sizeof(TC) == 2) {   // forward linears
     switch (k) { case EPI_BIAS: GO(EPI_BIAS); case EPI_RES: GO(EPI_RES); case EPI_RES_SCALE: GO(EPI_RES_SCALE); case EPI_GELU: GO(EPI_GELU);
                  case EPI_PATCH: GO(EPI_PATCH); case EPI_PLAIN: GO(EPI_PLAIN); case EPI_GELU_SG: GO(EPI_GELU_SG); }
@@ -662,46 +678,65 @@ static int launch_gemm(int tiles, const bf16_t* A, long lda, const bf16_t* Bm, l
 #undef GO
 }
 
+static int gemm_prob_ok(int kind, const GemmProb& p, int N, int K) {
+  // vector-width constraints of this kernel; anything else goes to the generic path
+  if (p.M <= 0) return 0;
+  if ((N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 7) || !aligned16(p.A) || !aligned16(p.B) || !aligned16(p.C)) return 0;
+  if (kind != FC_GEMM_TN && (K & 7)) return 0;
+  if (kind == FC_GEMM_TN && (p.M & 7)) return 0;
+  const GemmEpi& e = p.e;
+  if (e.bias && !aligned16(e.bias)) return 0;
+  if (e.res && !aligned16(e.res)) return 0;
+  if (e.preact && !aligned16(e.preact)) return 0;
+  if (e.gelu_in && !aligned16(e.gelu_in)) return 0;
+  if (e.pos && !aligned16(e.pos)) return 0;
+  return 1;
+}
+// one or two problems (same N, K, epilogue kind) in one launch; returns 1 when not covered (the caller launches them one by one)
+int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t s) {
+  if (FC_ABLATED("gemm")) return 0;
+  if (nprob < 1 || nprob > 2 || g.N <= 0 || g.K <= 0) return 1;
+  const int ek = epi_kind(g.p[0].e);
+  for (int i = 0; i < nprob; ++i) {
+    if (!gemm_prob_ok(kind, g.p[i], g.N, g.K)) return 1;
+    if (epi_kind(g.p[i].e) != ek) return 1;
+#ifdef FC_PROBES
+    static const int dbg = getenv("FC_GEMM_DBG") ? atoi(getenv("FC_GEMM_DBG")) : 0;
+    g.p[i].e.dbg = dbg;
+#endif
+  }
+  g.tiles_n = fc_cdiv(g.N, BN);
+  g.tiles0 = fc_cdiv(g.p[0].M, BM) * g.tiles_n;
+  g.ntiles = g.tiles0 + (nprob > 1 ? fc_cdiv(g.p[1].M, BM) * g.tiles_n : 0);
+  if (nprob == 1) g.p[1] = g.p[0];
+  if (kind == FC_GEMM_NT) {
+    if (dtC == FC_BF16) return launch_gemm<KC, KC, bf16_t>(g, ek, s);
+    return launch_gemm<KC, KC, float>(g, ek, s);
+  }
+  if (kind == FC_GEMM_NN) {
+    if (dtC == FC_BF16) return launch_gemm<KC, KR, bf16_t>(g, ek, s);
+    return launch_gemm<KC, KR, float>(g, ek, s);
+  }
+  // TN (weight gradients normally go through fc_gemm_tn_grouped instead)
+  if (dtC != FC_F32) return 1;
+  return launch_gemm<KR, KR, float>(g, ek, s);
+}
+
 int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K,
                  const GemmEpi& epi_in, hipStream_t s) {
   if (FC_ABLATED("gemm")) return 0;
-  const GemmEpi& epi0 = epi_in;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  // vector-width constraints of this kernel; anything else goes to the generic path
-  if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 7) || !aligned16(A) || !aligned16(Bm) || !aligned16(C)) return 1;
-  if (kind != FC_GEMM_TN && (K & 7)) return 1;
-  if (kind == FC_GEMM_TN && (M & 7)) return 1;
-  if (epi0.bias && !aligned16(epi0.bias)) return 1;
-  if (epi0.res && !aligned16(epi0.res)) return 1;
-  if (epi0.preact && !aligned16(epi0.preact)) return 1;
-  if (epi0.gelu_in && !aligned16(epi0.gelu_in)) return 1;
-  if (epi0.pos && !aligned16(epi0.pos)) return 1;
-  // FC_GEMM_WS: 0 (default) tiled kernel only; 1 weight-stationary kernel wherever it applies (K = 384); 2 only for N >= 1024;
-  // 3 additionally only for M >= 8192.  Stand-alone the weight-stationary kernel is 18-23 % faster on the N = 1536 shapes, inside
-  // the four-stream client step (where 160-KB workgroups cannot share a CU with another stream's kernels) it is 0-4 % slower:
-  // DESIGN.md section 3.
+  GemmGroup g{};
+  g.p[0] = GemmProb{A, Bm, C, lda, ldb, ldc, M, epi_in};
+  g.N = N; g.K = K;
+#ifdef FC_PROBES
+  // FC_GEMM_WS (tools build): 1 weight-stationary kernel wherever it applies (K = 384); 2 only for N >= 1024; 3 additionally only for
+  // M >= 8192.  Stand-alone it is 18-23 % faster on the N = 1536 shapes, inside the client step 0-4 % slower: DESIGN.md section 3.
   static const int use_ws = getenv("FC_GEMM_WS") ? atoi(getenv("FC_GEMM_WS")) : 0;
-  if (use_ws && dtC == FC_BF16 && kind != FC_GEMM_TN && (use_ws == 1 || N >= 1024) && (use_ws < 3 || M >= 8192)) {   // K <= 384: weight-stationary kernel (fc_gemm_ws.hip)
-    int r = fc_gemm_ws(kind, A, lda, Bm, ldb, (bf16_t*)C, ldc, M, N, K, epi0, s);
+  if (use_ws && dtC == FC_BF16 && kind != FC_GEMM_TN && gemm_prob_ok(kind, g.p[0], N, K) && (use_ws == 1 || N >= 1024) && (use_ws < 3 || M >= 8192)) {
+    int r = fc_gemm_ws(kind, A, lda, Bm, ldb, (bf16_t*)C, ldc, M, N, K, epi_in, s);
     if (r <= 0) return r;
   }
-  int tiles_n = fc_cdiv(N, BN);
-  int tiles = fc_cdiv(M, BM) * tiles_n;
-  GemmEpi epi = epi_in;
-#ifdef FC_PROBES
-  static const int dbg = getenv("FC_GEMM_DBG") ? atoi(getenv("FC_GEMM_DBG")) : 0;
-  epi.dbg = dbg;
 #endif
-  if (kind == FC_GEMM_NT) {
-    if (dtC == FC_BF16) return launch_gemm<KC, KC, bf16_t>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
-    return launch_gemm<KC, KC, float>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
-  }
-  if (kind == FC_GEMM_NN) {
-    if (dtC == FC_BF16) return launch_gemm<KC, KR, bf16_t>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
-    return launch_gemm<KC, KR, float>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
-  }
-  // single TN problem (weight gradients normally go through fc_gemm_tn_grouped instead)
-  if (dtC != FC_F32) return 1;
-  return launch_gemm<KR, KR, float>(tiles, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, epi, s);
+  return fc_gemm_mfma_grouped(kind, dtC, g, 1, s);
 }
-

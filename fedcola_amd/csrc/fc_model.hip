@@ -6,6 +6,7 @@
 
 #include <string>
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "../../include/fedcola_hip.h"
@@ -45,6 +46,7 @@ struct TowerP {
 struct LastFwd { const void* ws = nullptr; int B = 0, n_txt = 0, feat_out = 0; const float* droppath = nullptr; const int64_t* ids = nullptr; };
 struct fc_model {
   mutable LastFwd last;
+  mutable int last_ntxt = 0;
   mutable std::vector<FcTnProblem> probs_host;   // last uploaded grouped-GEMM table (+ where it lives on the device)
   mutable const void* probs_dev = nullptr;
   mutable std::vector<FcLnReduce> ln_host;        // same for the grouped LayerNorm-gradient reduction
@@ -59,6 +61,8 @@ struct fc_model {
   mutable void* tables_dev = nullptr;
   mutable size_t tables_bytes = 0;
   // fused optimizer (fc_client_step): which segments the weight-gradient epilogue steps, and the chunk table of everything else
+  mutable std::vector<std::pair<int64_t, int64_t>> zero_runs;   // fc_client_step: (offset, count) runs of the gradient buffer that must be zeroed
+  mutable int cover_B = -1, cover_ntxt = -1;
   mutable std::vector<char> fused_host;
   mutable void* rest_dev = nullptr;
   mutable int rest_chunks = 0;
@@ -237,6 +241,8 @@ struct LayerWs {
 };
 struct TowerWs {
   int M = 0, N = 0;
+  int dp_off = 0;          // first sample of this (micro-batch) view in the drop-path table
+  size_t ln_stride = 0;    // floats between the partial sets of consecutive LayerNorm instances (sized for the full batch)
   void *patches = nullptr, *dtok = nullptr;
   float *emb_mean = nullptr, *emb_rstd = nullptr;
   std::vector<void*> x;
@@ -254,7 +260,7 @@ struct Ws {
   FcLnReduce* lntab;    // device array for the grouped LayerNorm-gradient reduction
   int max_probs, max_ln;
   int B, n_txt, feat_out;
-  int dp_stride = 0, dp_off = 0;   // drop-path table: samples per row / first sample of this (micro-batch) view
+  int dp_stride = 0;       // drop-path table: samples per row
   const float* droppath;
   const int64_t* ids;
   float* shared_g = nullptr;       // colearn_param == 'attn': the second tower's gradients of the shared Attention linears
@@ -334,7 +340,8 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
     t.dh = bp.take((size_t)t.M * D * es);
     t.dO = bp.take((size_t)t.M * D * es);
     t.delta = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * t.N);
-    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)4 * 2 * c.depth * fc_layernorm_bwd_partial_blocks(t.M) * 2 * D);   // x4: micro-batches
+    t.ln_stride = ((size_t)fc_layernorm_bwd_partial_blocks(t.M) + 1) * 2 * D;                  // (+1: a slice may round up once more)
+    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)2 * 2 * c.depth * t.ln_stride);   // x2: micro-batch chains
   }
   w.max_probs = 2 * (4 * c.depth + 1);
   w.probs = (FcTnProblem*)bp.take(sizeof(FcTnProblem) * w.max_probs);
@@ -344,13 +351,13 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
   w.shared_g = m->shared_hi > m->shared_lo ? (float*)bp.take(sizeof(float) * (size_t)(m->shared_hi - m->shared_lo)) : nullptr;
   w.bytes = bp.off;
   w.B = B; w.n_txt = n_txt;
-  w.dp_stride = B; w.dp_off = 0;
+  w.dp_stride = B;
 }
 
 // View of the workspace restricted to samples [b0, b0+bn) of tower i (micro-batch `mb`): every per-row pointer is advanced,
 // so the unchanged forward / backward code runs on the slice.  The image tower is processed as two such slices on two
 // streams: the chains are independent until the loss, and their latency-bound kernels fill each other's gaps.
-static Ws slice_ws(const fc_model* m, const Ws& w, int i, int b0, int bn, int mb) {
+static Ws slice_ws(const fc_model* m, const Ws& w, int i, int b0, int bn, int mb, bool both_towers_view = true) {
   Ws v = w;
   const fc_model_cfg& c = m->cfg;
   const size_t es = fc_esize(m->dt);
@@ -384,9 +391,9 @@ static Ws slice_ws(const fc_model* m, const Ws& w, int i, int b0, int bn, int mb
   t.logits = f.logits + (size_t)b0 * nc; t.dlogits = f.dlogits + (size_t)b0 * nc; t.df = f.df + (size_t)b0 * D;
   t.dh = adv(f.dh, D * es); t.dO = adv(f.dO, D * es);
   t.delta = f.delta + (size_t)b0 * H * N;
-  t.ln_partial = f.ln_partial + (size_t)mb * 2 * c.depth * fc_layernorm_bwd_partial_blocks(f.M) * 2 * D;
-  v.B = bn;
-  v.dp_off = w.dp_off + b0;
+  t.ln_partial = f.ln_partial + (size_t)mb * 2 * c.depth * f.ln_stride;
+  t.dp_off = f.dp_off + b0;
+  if (both_towers_view) v.B = bn;
   return v;
 }
 // first sample of micro-batch k of n.  Two chains split the batch 57 : 43 (FC_MB_FIRST, percent taken by the chain on the caller's
@@ -401,7 +408,7 @@ static int mb_begin(int B, int k, int n) {
 static int microbatches(const fc_model* m, int B) {
   static int req = getenv("FC_MICROBATCH") ? atoi(getenv("FC_MICROBATCH")) : 2;
   if (m->dt != FC_BF16 || req < 2 || B < 16) return 1;
-  int n = req > 4 ? 4 : req;
+  int n = req > 2 ? 2 : req;      // two chains at most: the LayerNorm-gradient reduction takes two partial sets per tensor
   if (B < 8 * n) n = 2;
   while (n > 1 && !m->mbs[n - 2]) --n;      // streams are created for the configured count only
   return n;
@@ -478,13 +485,23 @@ struct Ctx {
   bool no_wgrad = false;                       // micro-batch slice: the full-batch weight gradients are queued by the driver
   int n_more = 0;                              // flush_dw also orders the chunk after the other micro-batch chains' streams
   std::vector<FcLnReduce>* lnq = nullptr;      // non-null: LayerNorm dgamma/dbeta partials are queued likewise
+  int ln_accumulate = 1;                       // the grouped reduction adds to the gradient buffer (0: plain store, buffer not zeroed)
   float* gshared = nullptr;                    // colearn 'attn': base such that gshared + L.w is the side buffer's slot of a shared linear
   const FcAdamW* fopt = nullptr;               // non-null: the grouped weight-gradient launches also take the AdamW step of what they produce
   std::vector<char>* fused_seg = nullptr;      // ... and the segments they cover are flagged here
   int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res, void* dx, float* dg,
              float* db, int M, int D, float* partial, void* dx_scaled = nullptr, const float* rowscale = nullptr, int rps = 1) const {
     int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, lnq ? partial : nullptr, dx_scaled, rowscale, rps);
-    if (r == 1) { lnq->push_back(FcLnReduce{partial, dg, db, fc_layernorm_bwd_partial_blocks(M), D}); return 0; }
+    if (r == 1) {      // two micro-batch chains of one tower share dg / db: one entry, two partial sets (the reduction uses no atomics)
+      for (FcLnReduce& e : *lnq)
+        if (e.dg == dg) {
+          FC_REQUIRE(!e.partial2, "internal: more than two partial sets for one LayerNorm gradient");
+          e.partial2 = partial; e.nblocks2 = fc_layernorm_bwd_partial_blocks(M);
+          return 0;
+        }
+      lnq->push_back(FcLnReduce{partial, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, ln_accumulate});
+      return 0;
+    }
     return r;
   }
   const void* W(int64_t off) const { return wc + (size_t)off * es; }
@@ -536,16 +553,16 @@ struct Ctx {
 
 static const float* dp_ptr(const fc_model* m, const Ws& w, int tower, int layer, int branch) {
   if (!w.droppath) return nullptr;
-  return w.droppath + (((size_t)tower * m->cfg.depth + layer) * 2 + branch) * w.dp_stride + w.dp_off;
+  return w.droppath + (((size_t)tower * m->cfg.depth + layer) * 2 + branch) * w.dp_stride + w.t[tower].dp_off;
 }
 
 // ---------------------------------------------------------------- forward (mome.py:881-922)
-static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int64_t* ids, int feat_out, float* out) {
+static int tower_embed_fwd(const Ctx& c, Ws& w, int i, const float* img, const int64_t* ids) {
   const fc_model* m = c.m;
   const fc_model_cfg& cf = m->cfg;
   const TowerP& tp = m->tw[i];
   TowerWs& t = w.t[i];
-  const int D = cf.dim, B = w.B, N = t.N, M = t.M, Hd = cf.mlp_hidden;
+  const int D = cf.dim, N = t.N, B = t.M / N;
   const float* P = c.params;
   if (i == 0) {  // ImageEmbedding.forward mome.py:597-611
     int np = N - 1, kp = cf.in_chans * cf.patch * cf.patch;
@@ -561,6 +578,36 @@ static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int
     FC_TRY(fc_txt_embed_fwd(c.dt, ids, P + tp.word, P + tp.tpos, P + tp.ttype, P + tp.lnw, P + tp.lnb, t.x[0], t.emb_mean, t.emb_rstd, B, N, D,
                             cf.vocab, 1e-12f, c.s));
   }
+  return 0;
+}
+static int tower_head_fwd(const Ctx& c, Ws& w, int i, int feat_out, float* out) {
+  const fc_model* m = c.m;
+  const fc_model_cfg& cf = m->cfg;
+  const TowerP& tp = m->tw[i];
+  TowerWs& t = w.t[i];
+  const int D = cf.dim, N = t.N, B = t.M / N;
+  const float* P = c.params;
+  int normalize = feat_out || tp.task == FC_TASK_RTV;
+  FC_TRY(fc_head_fwd(c.dt, t.x[cf.depth], P + m->normw, P + m->normb, t.f, t.hmean, t.hrstd, t.nrm, t.out, B, N, D, 1e-6f, normalize, c.s));
+  if (normalize) {
+    if (out) FC_CHECK_HIP(hipMemcpyAsync(out, t.out, sizeof(float) * (size_t)B * D, hipMemcpyDeviceToDevice, c.s));
+  } else {
+    FC_REQUIRE(tp.task == FC_TASK_CLS && tp.head_w >= 0, "tower %d has no head for feat_out=0", i);
+    GemmEpi e;
+    e.bias = P + tp.head_b;
+    FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, t.f, D, 1, P + tp.head_w, 1, D, t.logits, tp.ncls, B, tp.ncls, D, e, c.s));
+    if (out) FC_CHECK_HIP(hipMemcpyAsync(out, t.logits, sizeof(float) * (size_t)B * tp.ncls, hipMemcpyDeviceToDevice, c.s));
+  }
+  return 0;
+}
+static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int64_t* ids, int feat_out, float* out) {
+  const fc_model* m = c.m;
+  const fc_model_cfg& cf = m->cfg;
+  const TowerP& tp = m->tw[i];
+  TowerWs& t = w.t[i];
+  const int D = cf.dim, N = t.N, M = t.M, B = M / N, Hd = cf.mlp_hidden;
+  const float* P = c.params;
+  FC_TRY(tower_embed_fwd(c, w, i, img, ids));
   for (int l = 0; l < cf.depth; ++l) {  // Block.forward mome.py:225-228
     const BlockP& b = tp.blocks[l];
     LayerWs& L = t.L[l];
@@ -575,17 +622,208 @@ static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int
     { GemmEpi e; e.bias = P + b.fc2.b; e.res = L.xmid; e.rowscale = dp_ptr(m, w, i, l, 1); e.rows_per_sample = N;
       FC_TRY(c.gemm_fwd(L.gact, c.W(b.fc2.w), t.x[l + 1], M, D, Hd, e)); }
   }
-  int normalize = feat_out || tp.task == FC_TASK_RTV;
-  FC_TRY(fc_head_fwd(c.dt, t.x[cf.depth], P + m->normw, P + m->normb, t.f, t.hmean, t.hrstd, t.nrm, t.out, B, N, D, 1e-6f, normalize, c.s));
-  if (normalize) {
-    if (out) FC_CHECK_HIP(hipMemcpyAsync(out, t.out, sizeof(float) * (size_t)B * D, hipMemcpyDeviceToDevice, c.s));
-  } else {
-    FC_REQUIRE(tp.task == FC_TASK_CLS && tp.head_w >= 0, "tower %d has no head for feat_out=0", i);
-    GemmEpi e;
-    e.bias = P + tp.head_b;
-    FC_TRY(fc_gemm_generic(FC_F32, FC_F32, FC_F32, t.f, D, 1, P + tp.head_w, 1, D, t.logits, tp.ncls, B, tp.ncls, D, e, c.s));
-    if (out) FC_CHECK_HIP(hipMemcpyAsync(out, t.logits, sizeof(float) * (size_t)B * tp.ncls, hipMemcpyDeviceToDevice, c.s));
+  return tower_head_fwd(c, w, i, feat_out, out);
+}
+
+// ---- chain schedule: the towers advance layer by layer in GROUPED launches on ONE stream (LayerNorm, the four linears and their dX
+// products each take the image and the text rows in one launch: one read of a weight matrix per linear instead of three, 345 instead
+// of 150 tiles for the N = 384 GEMMs, no hardware-queue lottery); the weight gradients still run as grouped chunks on their own stream.
+struct LnFwdD { const void* x; const float* g; const float* b; void* y; float* mean; float* rstd; int M; };
+static int ln_fwd_multi(const Ctx& c, const LnFwdD* d, int n, int D, float eps) {
+  bool ok = fc_layernorm_grouped_ok(D) && n <= 2;
+  for (int i = 0; i < n; ++i) ok = ok && !(((uintptr_t)d[i].x | (uintptr_t)d[i].y | (uintptr_t)d[i].g | (uintptr_t)d[i].b) & 15);
+  if (ok && !FC_ABLATED("ln")) {
+    FcLnFwdArgs a{};
+    for (int i = 0; i < n; ++i) a.p[i] = FcLnFwdP{d[i].x, d[i].y, d[i].g, d[i].b, d[i].mean, d[i].rstd, d[i].M, 0};
+    a.nprob = n; a.D = D; a.eps = eps;
+    return fc_layernorm_fwd_grouped(c.dt, a, c.s);
   }
+  for (int i = 0; i < n; ++i) FC_TRY(fc_layernorm_fwd(c.dt, d[i].x, d[i].g, d[i].b, d[i].y, d[i].mean, d[i].rstd, d[i].M, D, eps, c.s));
+  return 0;
+}
+struct LnBwdD {
+  const void* dy; const void* x; const float* mean; const float* rstd; const float* g; const void* res; void* dx; float* dg; float* db; int M;
+  float* partial; void* dx_scaled; const float* rowscale; int rps;
+};
+static int ln_bwd_multi(const Ctx& c, const LnBwdD* d, int n, int D) {
+  bool ok = fc_layernorm_grouped_ok(D) && n <= 2 && c.lnq;
+  for (int i = 0; i < n; ++i)
+    ok = ok && d[i].partial &&
+         !(((uintptr_t)d[i].dy | (uintptr_t)d[i].x | (uintptr_t)d[i].res | (uintptr_t)d[i].dx | (uintptr_t)d[i].g | (uintptr_t)d[i].partial | (uintptr_t)d[i].dx_scaled) & 15);
+  if (ok && !FC_ABLATED("ln")) {
+    FcLnBwdArgs a{};
+    for (int i = 0; i < n; ++i) {
+      a.p[i] = FcLnBwdP{d[i].dy, d[i].x, d[i].mean, d[i].rstd, d[i].g, d[i].res, d[i].dx, d[i].dx_scaled, d[i].rowscale, d[i].partial, d[i].rps, d[i].M, 0, 0};
+      bool merged = false;      // two chains of one tower share dg / db: one entry, two partial sets (the reduction uses no atomics)
+      for (FcLnReduce& e : *c.lnq)
+        if (e.dg == d[i].dg) {
+          FC_REQUIRE(!e.partial2, "internal: more than two partial sets for one LayerNorm gradient");
+          e.partial2 = d[i].partial; e.nblocks2 = fc_layernorm_bwd_partial_blocks(d[i].M);
+          merged = true;
+        }
+      if (!merged)
+        c.lnq->push_back(FcLnReduce{d[i].partial, nullptr, d[i].dg, d[i].db, fc_layernorm_bwd_partial_blocks(d[i].M), 0, D, c.ln_accumulate});
+    }
+    a.nprob = n; a.D = D;
+    return fc_layernorm_bwd_grouped(c.dt, a, c.s);
+  }
+  for (int i = 0; i < n; ++i)
+    FC_TRY(c.ln_bwd(d[i].dy, d[i].x, d[i].mean, d[i].rstd, d[i].g, d[i].res, d[i].dx, d[i].dg, d[i].db, d[i].M, D, d[i].partial, d[i].dx_scaled,
+                    d[i].rowscale, d[i].rps));
+  return 0;
+}
+// kind NT: C[M,N] = A[M,K] . W[N,K]^T (forward linear); kind NN: C[M,N] = A[M,K] . W[K,N] (dX = dY . W)
+struct GemmD { const void* A; const void* W; void* C; int M; GemmEpi e; };
+static int gemm_multi(const Ctx& c, int kind, const GemmD* d, int n, int N, int K) {
+  if (c.dt == FC_BF16 && n >= 1 && n <= 2) {
+    GemmGroup g{};
+    for (int i = 0; i < n; ++i)
+      g.p[i] = GemmProb{(const bf16_t*)d[i].A, (const bf16_t*)d[i].W, d[i].C, (long)K, kind == FC_GEMM_NT ? (long)K : (long)N, (long)N, d[i].M, d[i].e};
+    g.N = N; g.K = K;
+    int r = fc_gemm_mfma_grouped(kind, FC_BF16, g, n, c.s);
+    if (r <= 0) return r;
+  }
+  for (int i = 0; i < n; ++i) {
+    if (kind == FC_GEMM_NT) FC_TRY(c.gemm_fwd(d[i].A, d[i].W, d[i].C, d[i].M, N, K, d[i].e));
+    else FC_TRY(c.gemm_dx(d[i].A, d[i].W, d[i].C, d[i].M, K, N, d[i].e));
+  }
+  return 0;
+}
+
+struct TowerList { int n = 0; int idx[2] = {0, 0}; };
+static int chain_layer_forward(const Ctx& c, Ws& w, const TowerList& T, int l) {   // Block.forward mome.py:225-228, the listed towers per launch
+  const fc_model* m = c.m;
+  const fc_model_cfg& cf = m->cfg;
+  const int D = cf.dim, Hd = cf.mlp_hidden, nt = T.n;
+  const float* P = c.params;
+  const int* tw = T.idx;
+  LnFwdD ln[2];
+  GemmD gd[2];
+  for (int q = 0; q < nt; ++q) {
+    const BlockP& b = m->tw[tw[q]].blocks[l]; TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
+    ln[q] = LnFwdD{t.x[l], P + b.n1w, P + b.n1b, L.h1, L.mean1, L.rstd1, t.M};
+  }
+  FC_TRY(ln_fwd_multi(c, ln, nt, D, 1e-5f));
+  for (int q = 0; q < nt; ++q) {
+    const BlockP& b = m->tw[tw[q]].blocks[l]; TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
+    gd[q] = GemmD{L.h1, c.W(b.qkv.w), L.qkv, t.M, GemmEpi()};
+    gd[q].e.bias = P + b.qkv.b;
+  }
+  FC_TRY(gemm_multi(c, FC_GEMM_NT, gd, nt, 3 * D, D));
+  for (int q = 0; q < nt; ++q) {
+    TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
+    FC_TRY(c.attn_fwd(L.qkv, L.o, L.lse, t.M / t.N, t.N));
+  }
+  for (int q = 0; q < nt; ++q) {
+    const BlockP& b = m->tw[tw[q]].blocks[l]; TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
+    gd[q] = GemmD{L.o, c.W(b.proj.w), L.xmid, t.M, GemmEpi()};
+    gd[q].e.bias = P + b.proj.b; gd[q].e.res = t.x[l]; gd[q].e.rowscale = dp_ptr(m, w, tw[q], l, 0); gd[q].e.rows_per_sample = t.N;
+  }
+  FC_TRY(gemm_multi(c, FC_GEMM_NT, gd, nt, D, D));
+  for (int q = 0; q < nt; ++q) {
+    const BlockP& b = m->tw[tw[q]].blocks[l]; TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
+    ln[q] = LnFwdD{L.xmid, P + b.n2w, P + b.n2b, L.h2, L.mean2, L.rstd2, t.M};
+  }
+  FC_TRY(ln_fwd_multi(c, ln, nt, D, 1e-5f));
+  for (int q = 0; q < nt; ++q) {
+    const BlockP& b = m->tw[tw[q]].blocks[l]; TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
+    gd[q] = GemmD{L.h2, c.W(b.fc1.w), L.gact, t.M, GemmEpi()};
+    gd[q].e.bias = P + b.fc1.b; gd[q].e.preact = L.u; gd[q].e.gelu_saved_grad = (c.dt == FC_BF16);   // bf16: L.u holds gelu'(u)
+  }
+  FC_TRY(gemm_multi(c, FC_GEMM_NT, gd, nt, Hd, D));
+  for (int q = 0; q < nt; ++q) {
+    const BlockP& b = m->tw[tw[q]].blocks[l]; TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
+    gd[q] = GemmD{L.gact, c.W(b.fc2.w), t.x[l + 1], t.M, GemmEpi()};
+    gd[q].e.bias = P + b.fc2.b; gd[q].e.res = L.xmid; gd[q].e.rowscale = dp_ptr(m, w, tw[q], l, 1); gd[q].e.rows_per_sample = t.N;
+  }
+  return gemm_multi(c, FC_GEMM_NT, gd, nt, D, Hd);
+}
+// Schedules (FC_SCHEDULE): "chain2" (default) = two chains of grouped launches on two streams -- the first part of the image batch on the
+// caller's stream, the rest of it TOGETHER WITH the text tower on a second stream -- plus the weight-gradient stream; "chain" = ONE chain
+// (every launch takes all image and text rows); "streams" = the round-2 form (two image chains, the text tower on its own stream).
+enum { SCHED_CHAIN2 = 0, SCHED_CHAIN = 1, SCHED_STREAMS = 2 };
+static int schedule() {
+  static const int v = [] {
+    const char* e = getenv("FC_SCHEDULE");
+    if (e && strcmp(e, "streams") == 0) return (int)SCHED_STREAMS;
+    if (e && strcmp(e, "chain") == 0) return (int)SCHED_CHAIN;
+    return (int)SCHED_CHAIN2;
+  }();
+  return v;
+}
+static bool chain_schedule() { return schedule() != SCHED_STREAMS; }
+
+#ifdef FC_PROBES
+// tools build (FC_STEP_PHASES=1): when each internal stream finished its part of the forward / backward, before the joins
+static hipEvent_t g_stream_ev[64 * 8];
+static bool g_stream_on = false;
+static int g_stream_step = 0;
+#define FC_STREAM_EV(i, st) do { if (g_stream_on) (void)hipEventRecord(g_stream_ev[(g_stream_step & 63) * 8 + (i)], (st)); } while (0)
+#else
+#define FC_STREAM_EV(i, st) do {} while (0)
+#endif
+struct ChainPlan {           // how the batch is cut into chains: chain 0 = image samples [0, b0) on the caller's stream; chain 1 = image
+  int nchains = 1, b0 = 0;   // samples [b0, B) and the whole text tower on the second stream (nchains == 1: everything on the caller's)
+};
+static int ensure_side(const fc_model* m, hipStream_t caller);
+static ChainPlan chain_plan(const fc_model* m, int B, bool run_img, bool run_txt) {
+  ChainPlan p;
+  static const int first = getenv("FC_MB_FIRST") ? atoi(getenv("FC_MB_FIRST")) : 0;
+  if (schedule() != SCHED_CHAIN2 || !run_img || m->dt != FC_BF16 || B < 16 || !m->mbs[0]) return p;
+  // equal rows per chain with the text tower (B x n_txt rows) on the second one; image only: 57 : 43 (equal chains run in lockstep and
+  // collide phase by phase, round 2)
+  int pct = first > 0 && first < 100 ? first : 57;
+  p.b0 = (int)((long)B * pct / 100);
+  if (run_txt && !(first > 0 && first < 100)) {
+    const int n_img = (m->cfg.img_size / m->cfg.patch) * (m->cfg.img_size / m->cfg.patch) + 1;
+    const long n_txt = m->last_ntxt > 0 ? m->last_ntxt : 32;
+    p.b0 = (int)(((long)B * (n_img + n_txt) + n_img) / (2L * n_img));
+  }
+  if (p.b0 < 1 || p.b0 > B - 1) return p;
+  p.nchains = 2;
+  return p;
+}
+static int chains_forward(const Ctx& c, Ws& w, const float* img, const int64_t* ids, int feat_out, float* out_img, float* out_txt) {
+  const fc_model* m = c.m;
+  const fc_model_cfg& cf = m->cfg;
+  const bool has_img = m->tw[0].present, has_txt = m->tw[1].present && !FC_ABLATED("txt");
+  FC_TRY(ensure_side(m, c.s));
+  m->last_ntxt = w.n_txt;
+  const ChainPlan pl = chain_plan(m, w.B, has_img, has_txt);
+  if (pl.nchains == 1) {
+    TowerList T;
+    if (has_img) T.idx[T.n++] = 0;
+    if (has_txt) T.idx[T.n++] = 1;
+    for (int q = 0; q < T.n; ++q) FC_TRY(tower_embed_fwd(c, w, T.idx[q], img, ids));
+    for (int l = 0; l < cf.depth; ++l) FC_TRY(chain_layer_forward(c, w, T, l));
+    for (int q = 0; q < T.n; ++q) FC_TRY(tower_head_fwd(c, w, T.idx[q], feat_out, T.idx[q] == 0 ? out_img : out_txt));
+    return 0;
+  }
+  const int b0 = pl.b0, B = w.B;
+  const size_t ipx = (size_t)cf.in_chans * cf.img_size * cf.img_size;
+  const size_t ow = (size_t)((feat_out || m->tw[0].task == FC_TASK_RTV) ? cf.dim : m->tw[0].ncls);
+  Ws wa = slice_ws(m, w, 0, 0, b0, 0, false), wb = slice_ws(m, w, 0, b0, B - b0, 1, false);
+  Ctx ca = c, cb = c;
+  cb.s = m->mbs[0];
+  TowerList TA, TB;
+  TA.idx[TA.n++] = 0;
+  TB.idx[TB.n++] = 0;
+  if (has_txt) TB.idx[TB.n++] = 1;
+  FC_CHECK_HIP(hipEventRecord(m->ev_fork, c.s));
+  FC_CHECK_HIP(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
+  FC_TRY(tower_embed_fwd(ca, wa, 0, img, nullptr));
+  FC_TRY(tower_embed_fwd(cb, wb, 0, img + (size_t)b0 * ipx, nullptr));
+  if (has_txt) FC_TRY(tower_embed_fwd(cb, wb, 1, nullptr, ids));
+  for (int l = 0; l < cf.depth; ++l) {
+    FC_TRY(chain_layer_forward(ca, wa, TA, l));
+    FC_TRY(chain_layer_forward(cb, wb, TB, l));
+  }
+  FC_TRY(tower_head_fwd(ca, wa, 0, feat_out, out_img));
+  FC_TRY(tower_head_fwd(cb, wb, 0, feat_out, out_img ? out_img + (size_t)b0 * ow : nullptr));
+  if (has_txt) FC_TRY(tower_head_fwd(cb, wb, 1, feat_out, out_txt));
+  FC_STREAM_EV(1, cb.s); FC_STREAM_EV(2, c.s);
+  FC_CHECK_HIP(hipEventRecord(m->ev_mb_join[0], cb.s));
+  FC_CHECK_HIP(hipStreamWaitEvent(c.s, m->ev_mb_join[0], 0));
   return 0;
 }
 
@@ -651,10 +889,17 @@ static StreamSet& device_streams(hipStream_t caller, int want) {
   (void)tested_ok;
   return S;
 }
-static int ensure_side(const fc_model* m, hipStream_t caller = nullptr) {
+static int ensure_side(const fc_model* m, hipStream_t caller) {
   if (!m->dws) {
+    if (chain_schedule()) {     // weight gradients, the second chain, the batch prefetcher's copy stream (fc_model_side_stream): with the
+      StreamSet& S = device_streams(caller, 3);   // caller's, the four hardware queues HIP drives
+      FC_REQUIRE(S.n >= 3, "could not create the internal HIP streams");
+      m->dws = S.s[0];
+      m->mbs[0] = schedule() == SCHED_CHAIN2 ? S.s[1] : nullptr;
+      m->side = S.s[2];
+    } else {
     static int req = getenv("FC_MICROBATCH") ? atoi(getenv("FC_MICROBATCH")) : 2;
-    const int nmb = (req > 4 ? 4 : (req < 1 ? 1 : req)) - 1;          // extra image chains
+    const int nmb = (req > 2 ? 2 : (req < 1 ? 1 : req)) - 1;          // extra image chains
     StreamSet& S = device_streams(caller, 2 + (nmb > 1 ? nmb : 1));
     FC_REQUIRE(S.n >= 3, "could not create the internal HIP streams");
     // order of preference for collision-free queues: weight gradients, first extra image chain, text tower
@@ -662,6 +907,7 @@ static int ensure_side(const fc_model* m, hipStream_t caller = nullptr) {
     m->mbs[0] = nmb >= 1 ? S.s[1] : nullptr;
     m->side = S.s[2];
     for (int k = 1; k < 3; ++k) m->mbs[k] = (k < nmb && 2 + k < S.n) ? S.s[2 + k] : nullptr;
+    }
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in, hipEventDisableTiming));
     for (int k = 0; k < 3; ++k) {
       FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_in2[k], hipEventDisableTiming));
@@ -675,7 +921,7 @@ static int ensure_side(const fc_model* m, hipStream_t caller = nullptr) {
   return 0;
 }
 extern "C" void* fc_model_side_stream(const fc_model_t* m) {
-  if (!m || ensure_side(m) != 0) return nullptr;
+  if (!m || ensure_side(m, nullptr) != 0) return nullptr;
   return (void*)m->side;
 }
 static int fork_side(const fc_model* m, hipStream_t s) {   // side (text tower) and micro-batch streams start after `s`
@@ -714,15 +960,6 @@ static int check_device(const void* p, const char* what) {
     (void)hipGetLastError();
   return 0;
 }
-#ifdef FC_PROBES
-// tools build (FC_STEP_PHASES=1): when each internal stream finished its part of the forward / backward, before the joins
-static hipEvent_t g_stream_ev[64 * 8];
-static bool g_stream_on = false;
-static int g_stream_step = 0;
-#define FC_STREAM_EV(i, st) do { if (g_stream_on) (void)hipEventRecord(g_stream_ev[(g_stream_step & 63) * 8 + (i)], (st)); } while (0)
-#else
-#define FC_STREAM_EV(i, st) do {} while (0)
-#endif
 static int ensure_tables(const fc_model* m, const Ws& w, hipStream_t s, FcTnProblem** probs, FcLnReduce** lntab) {
   const size_t need_p = sizeof(FcTnProblem) * (size_t)w.max_probs, need = need_p + sizeof(FcLnReduce) * (size_t)w.max_ln;
   if (m->tables_bytes < need) {      // first backward of this handle (or a deeper model than before): one small allocation, kept
@@ -751,6 +988,7 @@ static int forward_impl(const fc_model* m, const float* params, const void* wc, 
   FC_TRY(check_ws(m, B, m->tw[1].present ? n_txt : 0, workspace, wbytes, w));
   w.feat_out = feat_out; w.droppath = droppath; w.ids = ids;
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
+  if (chain_schedule()) return chains_forward(c, w, img, ids, feat_out, out_img, out_txt);
   const bool both = m->tw[0].present && m->tw[1].present;
   const int nmb = m->tw[0].present ? microbatches(m, B) : 1;
   if (both || nmb > 1) {   // text tower on the side stream, image tower as two micro-batch chains on two more streams (also without a text tower)
@@ -898,7 +1136,7 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
   const fc_model_cfg& cf = m->cfg;
   const TowerP& tp = m->tw[i];
   TowerWs& t = w.t[i];
-  const int D = cf.dim, B = w.B, N = t.N, M = t.M, Hd = cf.mlp_hidden;
+  const int D = cf.dim, N = t.N, M = t.M, B = M / N, Hd = cf.mlp_hidden;
   const float* P = c.params;
   int normalize = w.feat_out || tp.task == FC_TASK_RTV;
   const float* din = d_out;
@@ -941,7 +1179,7 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
     FC_TRY(linear_bwd_params(c, b.fc2, dm, L.gact, M, grads));
     { GemmEpi e; e.gelu_in = L.u; e.gelu_saved_grad = (c.dt == FC_BF16); FC_TRY(c.gemm_dx(dm, c.W(b.fc2.w), L.gdu, M, D, Hd, e)); }                  // du = (dm.W2) * gelu'(u)
     FC_TRY(linear_bwd_params(c, b.fc1, L.gdu, L.h2, M, grads));
-    const size_t lnp = (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D;
+    const size_t lnp = t.ln_stride;
     { GemmEpi e; FC_TRY(c.gemm_dx(L.gdu, c.W(b.fc1.w), t.dh, M, Hd, D, e)); }                                  // dh2
     // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp); da = gxmid * s1 comes out of the same LayerNorm-backward pass
     const float* s1 = dp_ptr(m, w, i, l, 0);
@@ -976,6 +1214,81 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
   return 0;
 }
 
+// Chain schedules, backward of layer l for the listed towers: every LayerNorm backward and every dX product takes all their rows in one
+// launch; the weight gradients are queued through linear_bwd_params (a micro-batch chain runs with no_wgrad: the driver queues them
+// over the full batch).
+static int chain_layer_backward(const Ctx& c, Ws& w, const TowerList& T, int l, float* grads) {
+  const fc_model* m = c.m;
+  const fc_model_cfg& cf = m->cfg;
+  const int D = cf.dim, Hd = cf.mlp_hidden, nt = T.n;
+  const float* P = c.params;
+  const int* tw = T.idx;
+  LnBwdD ln[2];
+  GemmD gd[2];
+  const void* dm[2];
+  const void* da[2];
+  // ---- MLP branch: x_{l+1} = xmid + s2 * (gact.W2^T + b2);  dm = dx * s2 (written by the LayerNorm backward above it, or here for the top layer)
+  for (int q = 0; q < nt; ++q) {
+    const int i = tw[q];
+    const BlockP& b = m->tw[i].blocks[l]; TowerWs& t = w.t[i]; LayerWs& L = t.L[l];
+    const float* s2 = dp_ptr(m, w, i, l, 1);
+    dm[q] = t.gx[l + 1];
+    if (s2) {
+      if (l == cf.depth - 1) FC_TRY(fc_rowscale(c.dt, t.gx[l + 1], L.gdm, s2, t.N, t.M, D, c.s));
+      dm[q] = L.gdm;
+    }
+    FC_TRY(linear_bwd_params(c, b.fc2, dm[q], L.gact, t.M, grads));
+    gd[q] = GemmD{dm[q], c.W(b.fc2.w), L.gdu, t.M, GemmEpi()};
+    gd[q].e.gelu_in = L.u; gd[q].e.gelu_saved_grad = (c.dt == FC_BF16);                 // du = (dm.W2) * gelu'(u)
+  }
+  FC_TRY(gemm_multi(c, FC_GEMM_NN, gd, nt, Hd, D));
+  for (int q = 0; q < nt; ++q) {
+    const int i = tw[q];
+    const BlockP& b = m->tw[i].blocks[l]; TowerWs& t = w.t[i]; LayerWs& L = t.L[l];
+    FC_TRY(linear_bwd_params(c, b.fc1, L.gdu, L.h2, t.M, grads));
+    gd[q] = GemmD{L.gdu, c.W(b.fc1.w), t.dh, t.M, GemmEpi()};                            // dh2
+  }
+  FC_TRY(gemm_multi(c, FC_GEMM_NN, gd, nt, D, Hd));
+  // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp); da = gxmid * s1 comes out of the same LayerNorm-backward pass
+  for (int q = 0; q < nt; ++q) {
+    const int i = tw[q];
+    const BlockP& b = m->tw[i].blocks[l]; TowerWs& t = w.t[i]; LayerWs& L = t.L[l];
+    const size_t lnp = (size_t)t.ln_stride;
+    const float* s1 = dp_ptr(m, w, i, l, 0);
+    ln[q] = LnBwdD{t.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, t.gx[l + 1], L.gxmid, grads + b.n2w, grads + b.n2b, t.M,
+                   t.ln_partial + (2 * l + 1) * lnp, s1 ? L.gda : nullptr, s1, t.N};
+    da[q] = s1 ? (const void*)L.gda : (const void*)L.gxmid;
+  }
+  FC_TRY(ln_bwd_multi(c, ln, nt, D));
+  for (int q = 0; q < nt; ++q) {
+    const int i = tw[q];
+    const BlockP& b = m->tw[i].blocks[l]; TowerWs& t = w.t[i]; LayerWs& L = t.L[l];
+    FC_TRY(linear_bwd_params(c, b.proj, da[q], L.o, t.M, grads));
+    gd[q] = GemmD{da[q], c.W(b.proj.w), t.dO, t.M, GemmEpi()};
+  }
+  FC_TRY(gemm_multi(c, FC_GEMM_NN, gd, nt, D, D));
+  for (int q = 0; q < nt; ++q) {
+    TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
+    FC_TRY(c.attn_bwd(L.qkv, L.o, t.dO, L.lse, t.delta, L.gdqkv, t.M / t.N, t.N));
+  }
+  for (int q = 0; q < nt; ++q) {
+    const int i = tw[q];
+    const BlockP& b = m->tw[i].blocks[l]; TowerWs& t = w.t[i]; LayerWs& L = t.L[l];
+    FC_TRY(linear_bwd_params(c, b.qkv, L.gdqkv, L.h1, t.M, grads));
+    gd[q] = GemmD{L.gdqkv, c.W(b.qkv.w), t.dh, t.M, GemmEpi()};                         // dh1
+  }
+  FC_TRY(gemm_multi(c, FC_GEMM_NN, gd, nt, D, 3 * D));
+  for (int q = 0; q < nt; ++q) {
+    const int i = tw[q];
+    const BlockP& b = m->tw[i].blocks[l]; TowerWs& t = w.t[i]; LayerWs& L = t.L[l];
+    const size_t lnp = (size_t)t.ln_stride;
+    const float* s2_below = l > 0 ? dp_ptr(m, w, i, l - 1, 1) : nullptr;      // the layer below wants gx[l] * s2(l-1) as its dm
+    ln[q] = LnBwdD{t.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, L.gxmid, t.gx[l], grads + b.n1w, grads + b.n1b, t.M,
+                   t.ln_partial + (2 * l) * lnp, s2_below ? t.L[l - 1].gdm : nullptr, s2_below, t.N};
+  }
+  return ln_bwd_multi(c, ln, nt, D);
+}
+
 // CrossModalReparamLinear: route dW_eff (mome.py:58-60).  Runs after the weight gradients exist (i.e. after the grouped launch).
 static int tower_reparam_grads(const Ctx& c, int i, float* grads) {
   // CrossModalReparamLinear: route dW_eff (mome.py:58-60) -- every re-param linear of the model in one launch (re-param models are
@@ -993,9 +1306,13 @@ struct LateDw {
   bool fused = false;             // fused optimizer: no segment waits for a chunk; the caller waits for ev_dw_out once, at the end
   std::vector<char> late_seg;     // per segment: its gradient is written by the last chunk
 };
+// covered (optional, out): per segment, 1 when this backward OVERWRITES the segment's gradient with plain stores (grouped weight-gradient
+// launches, LayerNorm reductions with ln_store): the caller need not zero it beforehand
 static int backward_impl(const fc_model* m, const float* params, const void* wc, const float* d_out_img, const float* d_out_txt, float* grads,
-                         Ws& w, hipStream_t s, LateDw* late = nullptr, const FcAdamW* fopt = nullptr, std::vector<char>* fused_seg = nullptr) {
+                         Ws& w, hipStream_t s, LateDw* late = nullptr, const FcAdamW* fopt = nullptr, std::vector<char>* fused_seg = nullptr,
+                         bool ln_store = false, std::vector<char>* covered = nullptr) {
   Ctx c{m, params, m->need_wc ? (const char*)wc : (const char*)params, s, m->dt, fc_esize(m->dt)};
+  c.ln_accumulate = ln_store ? 0 : 1;
   std::vector<FcTnProblem> probs;
   std::vector<FcLnReduce> lnq;
   DwState dwst;
@@ -1024,7 +1341,63 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
   }
   const bool run0 = m->tw[0].present && d_out_img, run1 = m->tw[1].present && d_out_txt;
   const int nmb = (run0 && c.defer) ? microbatches(m, w.B) : 1;
-  if (run0 && (run1 || nmb > 1)) {
+  if (chain_schedule()) {
+    const bool r1 = run1 && !FC_ABLATED("txt");
+    const ChainPlan pl = chain_plan(m, w.B, run0, r1);
+    const fc_model_cfg& cf = m->cfg;
+    if (pl.nchains == 1) {
+      TowerList T;
+      if (run0) T.idx[T.n++] = 0;
+      if (r1) T.idx[T.n++] = 1;
+      const float* const douts[2] = {d_out_img, d_out_txt};
+      for (int q = 0; q < T.n; ++q) FC_TRY(tower_backward(c, w, T.idx[q], douts[T.idx[q]], grads, PH_HEAD));
+      for (int l = cf.depth - 1; l >= 0; --l) {
+        FC_TRY(chain_layer_backward(c, w, T, l, grads));
+        if (dw_flush_here(l)) FC_TRY(flush_dw(c));   // this chunk's weight gradients (all towers) start now, under the layers below
+      }
+      for (int q = 0; q < T.n; ++q) FC_TRY(tower_backward(c, w, T.idx[q], douts[T.idx[q]], grads, PH_EMBED));
+      FC_TRY(flush_dw(c));
+    } else {
+      const int b0 = pl.b0, B = w.B;
+      const size_t ow = (size_t)((w.feat_out || m->tw[0].task == FC_TASK_RTV) ? cf.dim : m->tw[0].ncls);
+      // a classification head's weight gradients ACCUMULATE (generic GEMM, colsum): the head of the full batch on the caller's stream
+      // before the chains fork, instead of once per chain on concurrent streams
+      const bool cls_head = !(w.feat_out || m->tw[0].task == FC_TASK_RTV);
+      if (cls_head) FC_TRY(tower_backward(c, w, 0, d_out_img, grads, PH_HEAD));
+      Ws wa = slice_ws(m, w, 0, 0, b0, 0, false), wb = slice_ws(m, w, 0, b0, B - b0, 1, false);
+      Ctx ca = c, cb = c, cf_ = c;
+      ca.no_wgrad = cb.no_wgrad = true;
+      cb.s = m->mbs[0];
+      cf_.n_more = 1;
+      TowerList TA, TB;
+      TA.idx[TA.n++] = 0;
+      TB.idx[TB.n++] = 0;
+      if (r1) TB.idx[TB.n++] = 1;
+      FC_CHECK_HIP(hipEventRecord(m->ev_fork, s));
+      FC_CHECK_HIP(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
+      const float* dob = d_out_img + (size_t)b0 * ow;
+      if (!cls_head) {
+        FC_TRY(tower_backward(ca, wa, 0, d_out_img, grads, PH_HEAD));
+        FC_TRY(tower_backward(cb, wb, 0, dob, grads, PH_HEAD));
+      }
+      if (r1) FC_TRY(tower_backward(cb, wb, 1, d_out_txt, grads, PH_HEAD));
+      for (int l = cf.depth - 1; l >= 0; --l) {
+        FC_TRY(chain_layer_backward(ca, wa, TA, l, grads));
+        FC_TRY(chain_layer_backward(cb, wb, TB, l, grads));
+        FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_LAYER, l));       // full-batch weight gradients of this layer
+        if (r1) FC_TRY(tower_backward(cf_, w, 1, d_out_txt, grads, PH_WGRAD_LAYER, l));
+        if (dw_flush_here(l)) FC_TRY(flush_dw(cf_));
+      }
+      FC_TRY(tower_backward(ca, wa, 0, d_out_img, grads, PH_EMBED));
+      FC_TRY(tower_backward(cb, wb, 0, dob, grads, PH_EMBED));
+      if (r1) FC_TRY(tower_backward(cb, wb, 1, d_out_txt, grads, PH_EMBED));
+      FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_EMBED));
+      FC_TRY(flush_dw(cf_));
+      FC_STREAM_EV(4, cb.s); FC_STREAM_EV(5, s);
+      FC_CHECK_HIP(hipEventRecord(m->ev_mb_join[0], cb.s));
+      FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_mb_join[0], 0));
+    }
+  } else if (run0 && (run1 || nmb > 1)) {
     // a classification head's weight gradients ACCUMULATE (generic GEMM, colsum): take the head of the full batch on the caller's
     // stream before the chains fork, instead of once per chain on concurrent streams
     const bool cls_head = !(w.feat_out || m->tw[0].task == FC_TASK_RTV);
@@ -1090,6 +1463,18 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
   } else {
     if (run0) FC_TRY(tower_backward(c, w, 0, d_out_img, grads));
     if (run1) FC_TRY(tower_backward(c, w, 1, d_out_txt, grads));
+  }
+  if (covered) {
+    covered->assign(m->segs.size(), 0);
+    auto mark = [&](const float* p) {
+      if (!p || p < grads || p >= grads + m->total) return;
+      const int64_t off = p - grads;
+      size_t lo = 0, hi = m->segs.size();
+      while (lo + 1 < hi) { const size_t mid = (lo + hi) / 2; if (m->segs[mid].offset <= off) lo = mid; else hi = mid; }
+      if (m->segs[lo].offset == off) (*covered)[lo] = 1;
+    };
+    for (const FcTnProblem& q : probs) { mark(q.C); mark(q.bias_grad); }
+    if (ln_store) for (const FcLnReduce& e : lnq) { mark(e.dg); mark(e.db); }
   }
   if (!lnq.empty()) {
     FC_REQUIRE((int)lnq.size() <= w.max_ln, "internal: too many queued LayerNorm reductions");
@@ -1350,7 +1735,15 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
   bool both = m->tw[0].present && m->tw[1].present;
   if (!both) FC_REQUIRE(labels != nullptr, "fc_client_step: uni-modal clients need labels");
   Ws w;
-  FC_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->total, s));   // optimizer.zero_grad() fedavgclient.py:79
+  // optimizer.zero_grad() fedavgclient.py:79 -- only what the backward ACCUMULATES into (embeddings, the shared final norm, heads, re-param
+  // routing): the linears' and the blocks' LayerNorm gradients (93 % of the buffer) are overwritten by plain stores.  Which segments those
+  // are is recorded by the first step of a handle (which zeroes everything) and depends on the model and the batch shape only.
+  const bool know_cover = m->cover_B == B && m->cover_ntxt == n_txt && !m->zero_runs.empty();
+  if (know_cover) {
+    for (const std::pair<int64_t, int64_t>& r : m->zero_runs) FC_CHECK_HIP(hipMemsetAsync(grads + r.first, 0, sizeof(float) * (size_t)r.second, s));
+  } else {
+    FC_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->total, s));
+  }
   FC_CHECK_HIP(hipMemsetAsync(lossbuf + 1, 0, sizeof(float), s));
   FC_TRY(forward_impl(m, params, wc, img, ids, B, n_txt, both ? 1 : 0, droppath, workspace, workspace_bytes, nullptr, nullptr, s, w));
   m->last = LastFwd{workspace, B, w.n_txt, both ? 1 : 0, droppath, ids};
@@ -1386,8 +1779,23 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
   std::vector<char> fseg;
   late.fused = fused;
   FC_PHASE(2);
+  std::vector<char> covered;
   FC_TRY(backward_impl(m, params, wc, d0, d1, grads, w, s, (fused || (late_opt && !aux_any && !global_params)) ? &late : nullptr,
-                       fused ? &fo : nullptr, &fseg));
+                       fused ? &fo : nullptr, &fseg, /*ln_store=*/true, know_cover ? nullptr : &covered));
+  if (!know_cover) {
+    m->zero_runs.clear();
+    int64_t beg = -1, end = -1;
+    for (size_t k = 0; k < m->segs.size(); ++k) {
+      if (covered[k]) continue;
+      const int64_t o = m->segs[k].offset, e = (k + 1 < m->segs.size()) ? m->segs[k + 1].offset : m->total;
+      if (beg >= 0 && o == end) { end = e; continue; }
+      if (beg >= 0) m->zero_runs.push_back({beg, end - beg});
+      beg = o; end = e;
+    }
+    if (beg >= 0) m->zero_runs.push_back({beg, end - beg});
+    if (m->zero_runs.empty()) m->zero_runs.push_back({0, 0});
+    m->cover_B = B; m->cover_ntxt = n_txt;
+  }
   FC_PHASE(3);
   if (global_params)   // FedproxClient.update: loss += mu * 0.5 * sum ||p - p_global||, before the optimizer step (fedproxclient.py:64-72)
     FC_TRY(fc_prox_term(m, params, global_params, mu, B, grads, lossbuf, prox_scratch, prox_scratch_bytes, stream));
@@ -1514,7 +1922,7 @@ extern "C" int fc_k_layernorm_bwd_partial(int32_t dt, const void* dy, const void
   int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, partial);
   if (r != 1) return r;
   // one-entry reduction table at the tail of `partial` (the grouped reduction adds into dg / db)
-  FcLnReduce e{partial, dg, db, fc_layernorm_bwd_partial_blocks(M), D};
+  FcLnReduce e{partial, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, 1};
   FcLnReduce* tab = (FcLnReduce*)(partial + (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D);
   FC_CHECK_HIP(hipMemcpyAsync(tab, &e, sizeof(e), hipMemcpyHostToDevice, s));
   FC_CHECK_HIP(hipStreamSynchronize(s));      // `e` is a stack temporary (test entry point)

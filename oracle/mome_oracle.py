@@ -222,7 +222,8 @@ def _acc(grads, k, g):
     grads[k] = g if k not in grads else grads[k] + g
 
 
-def block_bwd(p, pre: str, dx2: Tensor, c, heads: int, grads, aux_trained: bool, apre: Optional[str] = None):
+def block_bwd(p, pre: str, dx2: Tensor, c, heads: int, grads, aux_trained: bool, apre: Optional[str] = None, tap: Optional[dict] = None):
+    """tap (optional, out): the block's intermediate dY tensors (dm, du, dx1, da, dqkv) for layer-local parity tests."""
     apre = apre or pre            # shared Attention module: its gradients accumulate under the owner's keys
     B, N, D = dx2.shape
     d = D // heads
@@ -258,6 +259,8 @@ def block_bwd(p, pre: str, dx2: Tensor, c, heads: int, grads, aux_trained: bool,
     dq = (dS @ k) * scale                                                 # q was pre-scaled
     dk = dS.transpose(-2, -1) @ q
     dqkv = R(torch.stack([dq, dk, dV], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * D))
+    if tap is not None:
+        tap.update(dm=dm, du=du, dx1=dx1, da=da, dqkv=dqkv)
     dh1, dWq, dbq = linear_bwd(dqkv, c["h1"], c["Wqkv"])
     dh1 = R(dh1)
     _lin_grads(grads, p, apre + ".attn.qkv", dWq, dbq, aux_trained)

@@ -55,8 +55,13 @@ def test_vit_s_b64_step_vs_oracle(oracle_result, prec, otol, gtol):
     assert abs(loss - loss_o) <= max(otol, 1e-4) * max(1.0, abs(loss_o))
     worst = ("", 0.0)
     for k, go in grads_o.items():
+        gk = grads[k]
+        if k.endswith("attn.qkv.bias"):      # the key third has an exactly-zero true gradient (softmax shift invariance): rounding noise on both sides
+            D3 = go.numel() // 3
+            sel = torch.cat([torch.arange(0, D3), torch.arange(2 * D3, 3 * D3)])
+            gk, go = gk[sel], go[sel]
         scale = max(float(go.abs().max()), 1e-7)
-        rel = float((grads[k] - go).abs().max()) / scale
+        rel = float((gk - go).abs().max()) / scale
         if rel > worst[1]:
             worst = (k, rel)
     assert worst[1] <= gtol, f"worst gradient tensor {worst}"
@@ -95,8 +100,13 @@ def test_vit_b_width_step_vs_oracle(kind, prec, otol, gtol):
     for k, go in grads_o.items():
         if "cross_modal_scale" in k:
             continue                                   # cancellation-dominated scalar, bounded separately in test_gpu_model
+        gk = grads[k]
+        if k.endswith("attn.qkv.bias"):      # the key third has an exactly-zero true gradient (softmax shift invariance): rounding noise on both sides
+            D3 = go.numel() // 3
+            sel = torch.cat([torch.arange(0, D3), torch.arange(2 * D3, 3 * D3)])
+            gk, go = gk[sel], go[sel]
         scale = max(float(go.abs().max()), 1e-7)
-        rel = float((grads[k] - go).abs().max()) / scale
+        rel = float((gk - go).abs().max()) / scale
         gemm_like = k.endswith(("qkv.weight", "proj.weight", "fc1.weight", "fc2.weight", "aux_weight", "head.weight")) and "embeddings" not in k
         if gemm_like or prec == "fp32":
             worst = max(worst, (k, rel), key=lambda t: t[1])

@@ -204,14 +204,17 @@ def test_cast_bf16_rne():
 
 
 def test_weight_stationary_gemm_opt_in_path(tmp_path):
-    """The K = 384 weight-stationary kernels (fc_gemm_ws.hip) are opt-in (FC_GEMM_WS=1, read once per process): run the GEMM and
-    model parity tests in a child process with the switch on, so that the path stays correct although the default step does not
-    take it (faster stand-alone on the N = 1536 shapes, not inside the multi-stream step)."""
+    """The K = 384 weight-stationary kernels (fc_gemm_ws.hip) are an experiment kept in the tools build only (-DFC_PROBES,
+    FC_PROBES_LIB=1 FC_GEMM_WS=1, read once per process): run the GEMM and model parity tests in a child process with the switch on,
+    so that the path stays correct although the product step does not take it (faster stand-alone on the
+    N = 1536 shapes, not inside the multi-stream step)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FC_GEMM_WS="1")
+    if not os.path.exists(os.path.join(root, "fedcola_amd", "libfedcola_hip_probes.so")):
+        pytest.skip("tools build (python -m fedcola_amd.build --probes) not present")
+    env = dict(os.environ, FC_GEMM_WS="1", FC_PROBES_LIB="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_kernels.py"),
                         os.path.join(root, "tests", "test_gpu_bf16_parity.py"), "-k", "test_gemm or layer_by_layer"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)

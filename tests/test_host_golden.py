@@ -163,7 +163,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fedcola_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.fc_abi_version() == 3
+    assert lib.fc_abi_version() == 4
 
 
 def test_model_layout_and_errors_without_gpu():
@@ -191,7 +191,7 @@ def test_header_is_plain_c(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     src = tmp_path / "t.c"
-    src.write_text('#include "fedcola_hip.h"\nint main(void) { fc_model_cfg c; (void)c; return FC_ABI_VERSION == 3 ? 0 : 1; }\n')
+    src.write_text('#include "fedcola_hip.h"\nint main(void) { fc_model_cfg c; (void)c; return FC_ABI_VERSION == 4 ? 0 : 1; }\n')
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
