@@ -15,6 +15,7 @@ independent during local epochs (weak scaling); the timed region ends with one F
 parameter buffer over xGMI).  Prints ONE JSON line (rank 0).
 """
 import argparse
+import copy
 import ctypes as C
 import hashlib
 import json
@@ -31,7 +32,7 @@ PAIR_GFLOP = 31.61           # algorithmic GEMM FLOPs per img-txt pair fwd+bwd, 
 STEP_ALG_GB = 10.8           # algorithmic HBM bytes per B=64 step, fully fused bf16
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 class Args:
@@ -62,8 +63,16 @@ def kernel_source_stamp():
 
 
 # The dominant kernel of the step (profiles/: largest share of kernel time): the NN dX GEMM k_gemm_mfma<KC,KR,bf16,PLAIN>, at the
-# shape the model launches it with most FLOPs: dh2 = gdu . W1 of one image micro-batch chain (M = 32*197 rows, N = 384, K = 1536).
-ROOF_KIND, ROOF_M, ROOF_N, ROOF_K = 1, 32 * 197, 384, 1536
+# shape the model launches it with most FLOPs: dh2 = gdu . W1 of the FIRST image micro-batch chain of the default schedule (57 % of
+# the B = 64 batch: 36 samples x 197 rows; the library's mb_begin() rule), N = 384, K = 1536.
+MB_FIRST_PCT = 57
+
+
+def roof_shape(B=64):
+    return 1, (B * MB_FIRST_PCT // 100) * 197, 384, 1536
+
+
+ROOF_KIND, ROOF_M, ROOF_N, ROOF_K = roof_shape()
 
 
 def gemm_roofline(steps=200):
@@ -99,8 +108,8 @@ def gemm_roofline(steps=200):
         if rec.get("source_stamp") == kernel_source_stamp() and rec.get("shape") == [ROOF_KIND, M, N, K]:
             traffic = rec.get("hbm_bytes_per_launch")
         else:
-            note = "profiles/r02/roofline_pmc.json was measured on other kernel sources / another shape: traffic withheld (re-run tools/collect_profiles.sh)"
-    out = dict(bound="mfma", kernel=f"k_gemm_mfma<KC,KR,bf16,PLAIN> (NN dX GEMM: dh2 = gdu.W1 of one image micro-batch chain) {M}x{N}x{K} bf16",
+            note = "profiles/r03/roofline_pmc.json was measured on other kernel sources / another shape: traffic withheld (re-run tools/collect_profiles.sh)"
+    out = dict(bound="mfma", kernel=f"k_gemm_mfma<KC,KR,bf16,PLAIN> (NN dX GEMM: dh2 = gdu.W1 of the first image micro-batch chain) {M}x{N}x{K} bf16",
                achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
                traffic=traffic, us_per_launch=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
                algorithmic_bytes_per_launch=alg_bytes, hbm_frac=round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
@@ -120,9 +129,10 @@ def cpu_model_name():
 
 
 def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
-    """Runs in a CHILD process (no GPU touched): the oracle's explicit fp32 client step on the host cores.
-    Protocol: fixed thread count = min(logical CPUs, 32) (torch's CPU GEMMs at these sizes stop scaling
-    there, and a fixed policy keeps runs comparable), `warm` warm-up steps, then `timed` steps -- cut short only by the time budget."""
+    """Runs in a CHILD process (no GPU touched): the oracle's fp32 client step on the host cores.
+    1. sweep: one warm-up + one timed step at {32, 64, 128, all} threads (those <= the logical CPUs), for both forms of the step --
+       explicit backward (O.client_step) and torch.autograd over the same forward (O.client_step_autograd: what the reference's
+       loss.backward() does); 2. `warm` warm-up + `timed` timed steps at the fastest (form, threads) -- cut short only by the budget."""
     import torch
     from oracle import mome_oracle as O
     from fedcola_amd.mome import create_model
@@ -130,8 +140,6 @@ def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
-    threads = max(1, min(cores, 32))
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
     a = Args()
     a.precision = "fp32"
@@ -139,22 +147,49 @@ def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
     p = {k: v.clone() for k, v in m.state_dict().items()}
     cfg = O.OracleCfg(D=384, depth=12, heads=6, vocab=vocab, max_text_len=seq)
     img, ids = make_batch(B, seq, vocab, 0, "cpu")
-    state = dict(step=0, m={}, v={})
+    forms = {"explicit": O.client_step, "autograd": O.client_step_autograd}
+    state = {f: dict(step=0, m={}, v={}) for f in forms}
     t_start = time.perf_counter()
+    sweep = {}
+
+    def one(f, t):
+        torch.set_num_threads(t)
+        forms[f](p, cfg, ("img+txt", img, ids), state[f], lr=1e-4)          # warm-up at this thread count
+        t0 = time.perf_counter()
+        forms[f](p, cfg, ("img+txt", img, ids), state[f], lr=1e-4)
+        sweep[f"{f}@{t}"] = round(time.perf_counter() - t0, 3)
+        return sweep[f"{f}@{t}"]
+    # thread counts in ascending order with the explicit form; stop when more threads are clearly slower or a third of the budget is
+    # gone (a 256-thread fp32 step can take 20 s on this host); then the autograd form at the best count
+    best_t, best_s = None, None
+    for t in sorted({t for t in (32, 64, 128, cores) if 1 <= t <= cores} or {cores}):
+        sec = one("explicit", t)
+        if best_s is None or sec < best_s:
+            best_t, best_s = t, sec
+        if sec > 1.25 * best_s or time.perf_counter() - t_start > budget_s / 3:
+            break
+    one("autograd", best_t)
+    best = min(sweep, key=sweep.get)
+    form, threads = best.split("@")[0], int(best.split("@")[1])
+    torch.set_num_threads(threads)
+    fn = forms[form]
     for _ in range(warm):
-        O.client_step(p, cfg, ("img+txt", img, ids), state, lr=1e-4)
+        fn(p, cfg, ("img+txt", img, ids), state[form], lr=1e-4)
     times = []
     for _ in range(timed):
         t0 = time.perf_counter()
-        O.client_step(p, cfg, ("img+txt", img, ids), state, lr=1e-4)
+        fn(p, cfg, ("img+txt", img, ids), state[form], lr=1e-4)
         times.append(time.perf_counter() - t0)
         if time.perf_counter() - t_start > budget_s and len(times) >= 5:
             break
     dt = sum(times) / len(times)
-    print(json.dumps(dict(value=round(B / dt, 2), unit="img-txt pairs/s", cores=threads, kind="port",
+    print(json.dumps(dict(value=round(B / dt, 2), unit="img-txt pairs/s", cores=threads, kind="port", form=form, sweep_s_per_step=sweep,
                           sample=f"{len(times)} timed + {warm} warm-up fp32 steps of the same B={B} ViT-S workload by oracle/mome_oracle.py "
-                                 f"(torch {torch.__version__} CPU ops, {threads} threads, {dt:.2f} s/step; host: {cpu_model_name()}, "
-                                 f"{os.cpu_count()} logical CPUs)")), flush=True)
+                                 f"({form} backward, torch {torch.__version__} CPU ops, {threads} threads = the fastest of the sweep "
+                                 f"{sweep}, {dt:.2f} s/step; host: {cpu_model_name()}, {os.cpu_count()} logical CPUs).  Both forms of the step "
+                                 f"are timed (explicit backward / torch.autograd over the same forward, as the reference's loss.backward()) "
+                                 f"and the faster is reported; the explicit form makes ~1.4x the elementwise passes and keeps every "
+                                 f"intermediate.  torch's fp32 CPU GEMMs at M = 12 608 stop scaling past a few dozen threads")), flush=True)
 
 
 def cpu_baseline(B, seq, vocab, timeout=420):
@@ -166,6 +201,110 @@ def cpu_baseline(B, seq, vocab, timeout=420):
         return json.loads(line[-1]) if line else dict(value=None, unit="img-txt pairs/s", kind="port", sample="child failed: " + out.stderr[-300:])
     except subprocess.TimeoutExpired:
         return dict(value=None, unit="img-txt pairs/s", kind="port", cores=None, sample=f"CPU baseline exceeded {timeout}s and was skipped")
+
+
+class InMemoryPairs:
+    """Flickr30k-shaped synthetic client data resident in host memory (tuple layout of src/datasets/flickr30k.py:42), pre-decoded:
+    get_batch gathers straight into the loader's pinned batch."""
+
+    def __init__(self, n, seq, vocab, seed=0):
+        import torch
+        g = torch.Generator().manual_seed(4000 + seed)
+        self.img = (torch.randn(n, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1)
+        self.ids = torch.randint(1, vocab, (n, seq), generator=g)
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return self.img[i], self.ids[i], i // 5, i, i
+
+    def get_batch(self, idxs, out=None):
+        import torch
+        i = torch.as_tensor(idxs)
+        if out is None:
+            return self.img[i], self.ids[i], i // 5, i, i
+        torch.index_select(self.img, 0, i, out=out[0])
+        torch.index_select(self.ids, 0, i, out=out[1])
+        out[2].copy_(i // 5); out[3].copy_(i); out[4].copy_(i)
+        return out
+
+
+def extra_legs(a, args, model, step, B, seq, dev, dev_step_s):
+    """h2d_inclusive: the same step with every batch coming from pinned host memory through DevicePrefetcher ("include H2D of
+    the batch (pinned, overlapped)").  client_round: FedavgClient.download() + update() (E = 1, 20 steps of B from an in-memory dataset
+    through the client's default loader) + the server's aggregation of that client, in pairs/s.  sustained: >= 2 s of back-to-back steps."""
+    import copy
+    import torch
+    from fedcola_amd.loaders import DevicePrefetcher
+    out = {}
+    # ---- h2d_inclusive
+    himg, hids = (torch.randn(B, 3, 224, 224) * 0.5).clamp_(-1, 1).pin_memory(), torch.randint(1, args.vocab_size, (B, seq)).pin_memory()
+    k = max(20, min(a.steps, 100))
+
+    def host_batches(nb):
+        for _ in range(nb):
+            yield himg, hids
+    it = iter(DevicePrefetcher(host_batches(k + 5), dev, depth=2, stream=model.side_stream()))
+    for _ in range(5):
+        step(next(it))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step(next(it))
+    torch.cuda.synchronize()
+    d = time.perf_counter() - t0
+    out["h2d_inclusive"] = dict(value=round(B * k / d, 1), unit="img-txt pairs/s", ms_per_step=round(d / k * 1e3, 3), steps=k,
+                                note="every batch copied from pinned host memory (38.5 MB) by DevicePrefetcher on the library's copy stream, two batches ahead")
+    # ---- sustained
+    t0 = time.perf_counter()
+    ks = 0
+    while time.perf_counter() - t0 < 2.0:
+        for _ in range(50):
+            step()
+        ks += 50
+        torch.cuda.synchronize()
+    d = time.perf_counter() - t0
+    out["sustained"] = dict(seconds=round(d, 2), steps=ks, ms_per_step=round(d / ks * 1e3, 3), value=round(B * ks / d, 1), unit="img-txt pairs/s")
+    # ---- client_round
+    from fedcola_amd import aggregate as agg
+    from fedcola_amd.client.fedavgclient import FedavgClient
+
+    class CArgs:
+        pass
+    ca = CArgs()
+    ca.__dict__.update(dict(vocab_size=args.vocab_size, seq_len=seq, dropout=args.dropout, optimizer="AdamW", lr=1e-4, weight_decay=0.0, E=1, B=B,
+                            no_shuffle=False, debug=False, with_aux=False, aux_attn_only=False, aux_mlp_only=False, max_grad_norm=0.0,
+                            distributed=False, mm_distributed=False, train_only=True))
+    nsteps = 20
+    ds = InMemoryPairs(nsteps * B, seq, args.vocab_size)
+    client = FedavgClient(ca, ds, ds, task="rtv", eval_metrics=[], modality="img+txt", criterion="ContrastiveLoss")
+    client._BaseClient__identifier = 0
+    client.dataset = "Flickr30k"
+    gmodel = copy.deepcopy(model)
+    keys = list(gmodel.required_params().keys())
+    plan = agg.build_plan(gmodel, [0], {k: {0: 1.0} for k in keys}, {0: gmodel.segments})
+    rounds = []
+    for r in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        client.download({"Flickr30k": gmodel})
+        t1 = time.perf_counter()
+        res = client.update()                     # ends with the per-epoch loss read: the device has finished the epoch
+        t2 = time.perf_counter()
+        agg.aggregate(gmodel, plan, {0: client.model.flat.data}, rank=0, world=1)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        rounds.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+    d, d_dl, d_up, d_ag = min(rounds[1:])
+    out["client_round"] = dict(value=round(nsteps * B / d, 1), unit="img-txt pairs/s", ms_per_round=round(d * 1e3, 2), ms_per_step=round(d / nsteps * 1e3, 3),
+                               steps_per_round=nsteps, vs_device_step=round(d / nsteps / dev_step_s, 3), epoch_loss=round(float(res[1]["loss"]), 4),
+                               loader=type(client.train_loader).__name__, download_ms=round(d_dl * 1e3, 2), update_ms=round(d_up * 1e3, 2),
+                               aggregate_ms=round(d_ag * 1e3, 2),
+                               note="FedavgClient.download() + update() (E = 1, 20 x B pairs from host memory through the client's default loader and "
+                                    "DevicePrefetcher, per-epoch loss read) + aggregation of the client into the global model; best of 2 rounds after a warm-up round")
+    return out
 
 
 def free_port():
@@ -204,8 +343,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropout-line", action="store_true")
-    ap.add_argument("--agg", default="torch", choices=["torch", "cabi"], help="cross-rank sum of the aggregation: torch.distributed.all_reduce "
-                    "(RCCL) or the C ABI's own RCCL communicator (fc_comm_* / fc_aggregate)")
+    ap.add_argument("--agg", default="cabi", choices=["torch", "cabi"], help="cross-rank sum of the timed aggregation: the C ABI's own RCCL "
+                    "communicator (fc_comm_* / fc_aggregate, default) or torch.distributed.all_reduce (RCCL); the other one runs once after "
+                    "the timed region as the cross-check (agg_paths_agree)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the h2d_inclusive / client_round / sustained legs (N = 1)")
     ap.add_argument("--h2d", action="store_true", help="non-default: batches start in pinned host memory and reach the GPU through "
                     "fedcola_amd.loaders.DevicePrefetcher (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--fedprox-mu", type=float, default=0.0, help="non-default workload: FedproxClient step (proximal term, row N3)")
@@ -215,7 +356,7 @@ def main():
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_child:
-        cpu_baseline_child(a.batch, Args.seq_len, Args.vocab_size, warm=3, timed=10, budget_s=300)
+        cpu_baseline_child(a.batch, Args.seq_len, Args.vocab_size, warm=3, timed=10, budget_s=240)
         return 0
     in_job = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if a.gpus > 1 and not in_job:
@@ -280,10 +421,12 @@ def main():
     dp_gen = torch.Generator(device=dev)
     dp_gen.manual_seed(77 + rank)
 
-    def step(drop_model=None):
+    def step(batch=None, drop_model=None):
         nonlocal img, ids
         if feed is not None:
             img, ids = next(feed)
+        if batch is not None:
+            img, ids = batch[0], batch[1]
         step_no[0] += 1
         mdl = drop_model or model
         dp = mdl.make_droppath(B, generator=dp_gen)       # None at rate 0; else timm DropPath multipliers drawn on the device
@@ -300,7 +443,6 @@ def main():
     plan = comm = None
     if world > 1:
         from fedcola_amd import aggregate as agg
-        import copy
         cids = list(range(world))                                          # one client per rank
         keys = list(model.required_params().keys())
         sizes = {i: 1280 for i in cids}                                    # equal client sizes, scope 'dataset'
@@ -309,18 +451,26 @@ def main():
         torch.manual_seed(1)                                               # the global model is identical on every rank
         global_model = create_model("mome_small_patch16", False, args=args, num_classes=[None, None], modalities=["img", "txt"],
                                     tasks=["rtv", "rtv"]).to(dev)
-        if a.agg == "cabi":
+        comm_c = None
+        if not (one_device and os.environ.get("FC_BENCH_BACKEND", "gloo") == "gloo"):     # RCCL refuses two ranks on one device
             from fedcola_amd.comm import Comm
-            comm = Comm.from_torch_dist()
+            comm_c = Comm.from_torch_dist()
+        comm = comm_c if a.agg == "cabi" else None
 
-    def aggregate(dump=None):
+    agg_state = {}
+
+    def aggregate(dump=None, keep=False):
         if world > 1:
+            if keep:                                                       # inputs of the self-validation below
+                agg_state["g_before"] = global_model.flat.data.clone()
+                agg_state["client"] = model.flat.data.clone()
             if dump:
                 os.makedirs(dump, exist_ok=True)
                 torch.save(model.flat.detach().cpu(), os.path.join(dump, f"client{rank}.pt"))
                 if rank == 0:
                     torch.save(global_model.flat.detach().cpu(), os.path.join(dump, "global_before.pt"))
             agg.aggregate(global_model, plan, {rank: model.flat.data}, rank=rank, world=world, comm=comm)
+            agg_state["g_after"] = global_model.flat.data
             if dump and rank == 0:
                 torch.save(global_model.flat.detach().cpu(), os.path.join(dump, "global_after.pt"))
                 json.dump(dict(keys=keys, coef={k: [coef[k][i] for i in cids] for k in keys}, segments={k: [s["offset"], s["numel"]] for k, s in model.segments.items()}),
@@ -344,10 +494,61 @@ def main():
     t_enq = time.perf_counter() - t0        # host time to enqueue the steps (launch-bound if close to dt)
     torch.cuda.synchronize()
     t_steps = time.perf_counter() - t0
-    aggregate(a.dump_agg)
+    aggregate(a.dump_agg, keep=True)
     barrier()
     dt = time.perf_counter() - t0
     per_rank = [dt]
+    # ---- N > 1: the line validates itself (the driver's 8-GPU run is the first execution of ncclAllReduce through fc_aggregate)
+    selfcheck = {}
+    if world > 1:
+        g_after = global_model.flat.data
+        # (a) every rank ends with the same global model
+        cs = torch.stack([g_after.double().sum(), g_after.double().abs().sum()])
+        all_cs = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(all_cs, cs)
+        same = all(bool(torch.equal(all_cs[0], c)) for c in all_cs)
+        # (b) rank 0 recomputes a 1-MB slice from the gathered client slices with plain torch ops (no oracle, no library kernel)
+        nsl = min(262144, n)
+        mine = agg_state["client"][:nsl].contiguous()
+        sl = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(sl, mine)
+        ok_slice = True
+        if rank == 0:
+            exp = torch.zeros(nsl, device=dev, dtype=torch.float64)
+            for sidx in range(len(plan.keys)):
+                o, ln = int(plan.seg_off[sidx]), int(plan.seg_len[sidx])
+                if o >= nsl:
+                    continue
+                e = min(o + ln, nsl)
+                w = plan.weights[sidx].double()
+                acc = w[0] * agg_state["g_before"][o:e].double()
+                for j in range(world):
+                    so = int(plan.src_off[sidx, j])
+                    if so >= 0 and float(w[1 + j]) != 0.0:
+                        acc = acc + w[1 + j] * sl[j][so:so + (e - o)].double()
+                exp[o:e] = acc
+            covered = torch.zeros(nsl, dtype=torch.bool, device=dev)
+            for sidx in range(len(plan.keys)):
+                o, ln = int(plan.seg_off[sidx]), int(plan.seg_len[sidx])
+                if o < nsl:
+                    covered[o:min(o + ln, nsl)] = True
+            err = (g_after[:nsl].double() - exp)[covered].abs().max()
+            ok_slice = bool(err <= 1e-6 * max(1.0, float(exp.abs().max())))
+        # (c) the other aggregation path on the same inputs
+        paths_agree = None
+        other = None if comm is not None else comm_c
+        if not (comm is None and comm_c is None):
+            g2 = copy.deepcopy(global_model)
+            g2.flat.data.copy_(agg_state["g_before"])
+            agg.aggregate(g2, plan, {rank: agg_state["client"]}, rank=rank, world=world, comm=other)
+            d = (g2.flat.data - g_after).abs().max()
+            paths_agree = bool(d <= 2e-6 * max(1.0, float(g_after.abs().max())))
+        flags = torch.tensor([int(same), int(ok_slice), int(paths_agree is not False)], device=dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        selfcheck = dict(rccl_ranks=dist.get_world_size(), comm_world=(int(_lib.lib().fc_comm_world(comm_c.h)) if comm_c is not None else None),
+                         agg_checksum_agree=bool(flags[0]) and bool(flags[1]), agg_all_ranks_equal=bool(flags[0]), agg_slice_recomputed_ok=bool(flags[1]),
+                         agg_paths_agree=(None if paths_agree is None else bool(flags[2])),
+                         agg_crosscheck_path=("torch.distributed.all_reduce" if comm is not None else ("C ABI fc_aggregate" if comm_c is not None else None)))
     if world > 1:
         t = torch.tensor([dt, t_steps], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(t) for _ in range(world)]
@@ -367,15 +568,20 @@ def main():
         dm.train()
         k2 = max(10, a.steps // 4)
         for _ in range(5):
-            step(dm)
+            step(drop_model=dm)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(k2):
-            step(dm)
+            step(drop_model=dm)
         torch.cuda.synchronize()
         d2 = time.perf_counter() - t1
         drop_line = dict(value=round(B * k2 / d2, 1), unit="img-txt pairs/s", ms_per_step=round(d2 / k2 * 1e3, 3), steps=k2, drop_path_rate=0.1,
                          note="reference default --dropout 0.1: per-sample DropPath multipliers drawn on the device every step")
+
+    # ---- N = 1: what the metric names ("per client round"), and a leg long enough for the driver's gpu_busy sampling
+    extra = {}
+    if rank == 0 and world == 1 and not a.no_extra_legs and not a.h2d and a.fedprox_mu == 0:
+        extra = extra_legs(a, args, model, step, B, seq, dev, dt / a.steps)
 
     if rank == 0:
         pairs = world * B * a.steps / dt
@@ -394,6 +600,13 @@ def main():
                    per_rank_ms_per_step=[round(x / a.steps * 1e3, 3) for x in per_rank],
                    aggregate_path=("none (1 client)" if world == 1 else ("C ABI fc_aggregate: HIP blend + ncclAllReduce" if comm is not None else
                                    "HIP blend + torch.distributed.all_reduce (" + dist.get_backend() + ")")))
+        if world > 1:
+            agg_s = max(dt - t_steps, 1e-9)
+            # ring all-reduce moves 2 (N-1)/N of the buffer through every link; GB/s per rank of payload = the figure xGMI is judged by
+            out["aggregate_GBps"] = round(4 * n / agg_s / 1e9, 2)
+            out["allreduce_bus_GBps"] = round(2 * (world - 1) / world * 4 * n / agg_s / 1e9, 2)
+            out.update(selfcheck)
+        out.update(extra)
         if drop_line is not None:
             out["dropout_0p1"] = drop_line
         if not a.no_roofline:
@@ -401,9 +614,9 @@ def main():
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
-    if comm is not None:
-        comm.close()
     if world > 1:
+        if comm_c is not None:
+            comm_c.close()
         dist.destroy_process_group()
     return 0
 

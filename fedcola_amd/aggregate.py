@@ -132,26 +132,47 @@ class BlendPlan:
     weights: torch.Tensor            # float32 [nseg, m+1]  (w_g, w_1..w_m)
 
 
+def _alias_map(model) -> Dict[str, str]:
+    """alias key -> key of the segment it views (sync_shared_weights: scope 'all' / colearn_param 'attn'); {} for plain models."""
+    f = getattr(model, "_alias_keys", None)
+    return dict(f()) if f is not None else {}
+
+
 def build_plan(global_model, ids: Sequence[int], coefficients, client_segments: Mapping[int, Mapping[str, dict]],
                zero_init: bool = False) -> BlendPlan:
-    """client_segments[i][key] -> {'offset':..} of the keys client i uploads (aux / scale keys already dropped).
-    zero_init: CreamflServer._aggregate (creamflserver.py:257-288) -- a plain weighted sum into zeros: w_g = 0, w_j = c_j."""
-    keys = list(coefficients.keys())
+    """client_segments[i][key] -> {'offset':..} of the keys client i uploads (aux / scale keys already dropped; alias keys of a
+    colearn_param == 'attn' model point at the owner's segment).
+    zero_init: CreamflServer._aggregate (creamflserver.py:257-288) -- a plain weighted sum into zeros: w_g = 0, w_j = c_j.
+
+    Alias keys: in the reference the two keys of a shared tensor ARE one tensor in ``final_sd`` (required_params() is a shallow copy
+    of state_dict(), mome.py:844-860), so the in-place loop (fedavgserver.py:656-664: clients outer, keys inner) blends it once per
+    key for every client: client 1 under the owner's key, client 1 again under the alias key, client 2 under the owner's key, ...
+    each step with that key's coefficient.  One plan row per tensor: the closed form over that interleaved sequence."""
+    alias = _alias_map(global_model)
+    gseg = global_model.segments
+    groups: "Dict[str, List[str]]" = {}
+    for k in coefficients.keys():
+        groups.setdefault(alias.get(k, k), []).append(k)
+    keys = list(groups.keys())
     m = len(ids)
     seg_off = torch.empty(len(keys), dtype=torch.int64)
     seg_len = torch.empty(len(keys), dtype=torch.int64)
     src_off = torch.full((len(keys), m), -1, dtype=torch.int64)
     weights = torch.zeros(len(keys), m + 1, dtype=torch.float32)
-    gseg = global_model.segments
-    for s, k in enumerate(keys):
-        seg_off[s] = gseg[k]["offset"]
-        seg_len[s] = gseg[k]["numel"]
-        part = [(j, i) for j, i in enumerate(ids) if k in client_segments[i] and coefficients[k][i] != 0]
-        wg, w = (0.0, [coefficients[k][i] for _, i in part]) if zero_init else effective_weights([coefficients[k][i] for _, i in part])
+    for s, owner in enumerate(keys):
+        seg_off[s] = gseg[owner]["offset"]
+        seg_len[s] = gseg[owner]["numel"]
+        if zero_init and len(groups[owner]) > 1:
+            raise NotImplementedError("zero-initialised aggregation of a model with shared (alias) tensors")
+        seq = [(j, i, k) for j, i in enumerate(ids) for k in groups[owner] if k in client_segments[i] and coefficients[k][i] != 0]
+        cs = [coefficients[k][i] for _, i, k in seq]
+        wg, w = (0.0, cs) if zero_init else effective_weights(cs)
         weights[s, 0] = wg
-        for (j, i), wj in zip(part, w):
-            weights[s, 1 + j] = wj
-            src_off[s, j] = client_segments[i][k]["offset"]
+        for (j, i, k), wj in zip(seq, w):
+            weights[s, 1 + j] += wj
+            off = int(client_segments[i][k]["offset"])
+            assert src_off[s, j] in (-1, off), "a client's keys of one shared tensor must point at one segment"
+            src_off[s, j] = off
     return BlendPlan(keys, list(ids), seg_off, seg_len, src_off, weights)
 
 
@@ -275,6 +296,48 @@ def aggregate(global_model, plan: BlendPlan, local_flats: Mapping[int, torch.Ten
     return global_model
 
 
+def aggregate_many(items, *, rank: int = 0, world: int = 1, all_reduce: Optional[Callable[[torch.Tensor], None]] = None, comm=None,
+                   local_partial=None):
+    """Several global models of one round (one per dataset, fedavgserver.py:812-819) with ONE cross-rank sum: every model's local
+    partial is blended into its range of a concatenated buffer, the buffer is all-reduced once (K models: one collective instead of K
+    -- on xGMI a ring all-reduce is latency- and per-link-bound, fewer and larger is the cheaper shape), and each model takes its
+    planned ranges back.  items: [(global_model, plan, local_flats)].  ``local_partial`` replaces the HIP blend (CPU tests)."""
+    if world == 1 or len(items) <= 1:
+        kw = {} if local_partial is None else {"local_partial": local_partial}
+        for gm, plan, flats in items:
+            aggregate(gm, plan, flats, rank=rank, world=world, all_reduce=all_reduce, comm=comm, **kw)
+        return
+    g0 = items[0][0].flat.data
+    total = sum(gm.flat.numel() for gm, _, _ in items)
+    owner = items[0][0]
+    cat = getattr(owner, "_agg_cat", None)
+    if cat is None or cat.device != g0.device or cat.numel() != total:
+        cat = torch.zeros(total, device=g0.device)      # zero once: ranges outside the plans stay zero through every all-reduce
+        owner._agg_cat = cat
+    off = 0
+    views = []
+    for gm, plan, flats in items:
+        n = gm.flat.numel()
+        if local_partial is None:
+            hip_local_partial(plan, gm.flat.data, flats, include_global=(rank == 0), out=cat[off:off + n])
+        else:
+            cat[off:off + n].copy_(local_partial(plan, gm.flat.data, flats, include_global=(rank == 0)))
+        views.append((gm, plan, cat[off:off + n]))
+        off += n
+    if comm is not None:
+        comm.all_reduce(cat)
+    else:
+        if all_reduce is None:
+            import torch.distributed as dist
+            all_reduce = dist.all_reduce
+        all_reduce(cat)
+    for gm, plan, part in views:
+        g = gm.flat.data
+        for o, e in _copy_runs(plan):
+            g[o:e].copy_(part[o:e])
+        gm._bump()
+
+
 def aggregate_exact(global_model, plan_keys: Sequence[str], ids: Sequence[int], coefficients, client_segments, local_flats, *, comm=None):
     """The reference's sequential in-place blend itself, in its order and rounding (``fc_aggregate_blend_seq`` /
     ``fc_aggregate_exact``): bit-identical to fedavgserver.py:656-664 in fp32.  Verification mode of the closed form.
@@ -286,30 +349,41 @@ def aggregate_exact(global_model, plan_keys: Sequence[str], ids: Sequence[int], 
     dev = g.device
     m = len(ids)
     gseg = global_model.segments
-    seg_off = torch.tensor([gseg[k]["offset"] for k in plan_keys], dtype=torch.int64)
-    seg_len = torch.tensor([gseg[k]["numel"] for k in plan_keys], dtype=torch.int64)
-    src = torch.full((len(plan_keys), m), -1, dtype=torch.int64)
-    coef = torch.zeros(len(plan_keys), m, dtype=torch.float32)
-    for s, k in enumerate(plan_keys):
-        for j, i in enumerate(ids):
-            if k in client_segments[i] and coefficients[k][i] != 0:
-                src[s, j] = client_segments[i][k]["offset"]
-                coef[s, j] = coefficients[k][i]
-    d = [t.to(dev) for t in (seg_off, seg_len, src.contiguous(), coef.contiguous())]
+    alias = _alias_map(global_model)
+    # a shared tensor listed under two keys is blended once per key for every client, clients outer (the reference's loop): each client
+    # becomes `nrep` consecutive virtual clients, one per occurrence of the tensor among the keys
+    groups: "Dict[str, List[str]]" = {}
+    for k in plan_keys:
+        groups.setdefault(alias.get(k, k), []).append(k)
+    owners = list(groups.keys())
+    nrep = max(len(v) for v in groups.values()) if groups else 1
     L = _lib.lib()
+    seg_off = torch.tensor([gseg[o]["offset"] for o in owners], dtype=torch.int64)
+    seg_len = torch.tensor([gseg[o]["numel"] for o in owners], dtype=torch.int64)
+    src = torch.full((len(owners), m * nrep), -1, dtype=torch.int64)
+    coef = torch.zeros(len(owners), m * nrep, dtype=torch.float32)
+    for s, o in enumerate(owners):
+        for j, i in enumerate(ids):
+            for r, k in enumerate(groups[o]):
+                if k in client_segments[i] and coefficients[k][i] != 0:
+                    src[s, j * nrep + r] = client_segments[i][k]["offset"]
+                    coef[s, j * nrep + r] = coefficients[k][i]
+    d = [t.to(dev) for t in (seg_off, seg_len, src.contiguous(), coef.contiguous())]
     if comm is None or comm.world == 1:
         assert all(i in local_flats for i in ids), "single-process exact blend needs every sampled client's weights"
-        arr = (C.c_void_p * max(m, 1))(*[local_flats[i].data_ptr() for i in ids])
-        check(L.fc_aggregate_blend_seq(ptr(g), arr, m, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), len(plan_keys), _lib.stream_ptr()))
+        assert m * nrep <= 64, "exact blend: too many (virtual) clients for one launch"
+        arr = (C.c_void_p * max(m * nrep, 1))(*[local_flats[i].data_ptr() for i in ids for _ in range(nrep)])
+        check(L.fc_aggregate_blend_seq(ptr(g), arr, m * nrep, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), len(owners), _lib.stream_ptr()))
     else:
         assert m == comm.world and len(local_flats) == 1, "exact mode across ranks: one client per rank"
+        assert nrep == 1, "exact mode across ranks: models with shared (alias) tensors are blended in a single process"
         (mine, flat), = local_flats.items()
         assert ids[comm.rank] == mine
         slot = max(max(int(sg["offset"]) + int(sg["numel"]) for sg in client_segments[i].values()) for i in ids)
         local = torch.zeros(slot, device=dev)
         local[: min(slot, flat.numel())].copy_(flat[: min(slot, flat.numel())])
         gathered = torch.empty(slot * comm.world, device=dev)
-        check(L.fc_aggregate_exact(comm.h, ptr(g), ptr(local), ptr(gathered), slot, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), len(plan_keys),
+        check(L.fc_aggregate_exact(comm.h, ptr(g), ptr(local), ptr(gathered), slot, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), len(owners),
                                    _lib.stream_ptr()))
     torch.cuda.current_stream().synchronize()            # the tables above are temporaries of this (verification) call
     global_model._bump()

@@ -51,10 +51,12 @@ class FedavgClient(BaseClient):
             self.args.B = len(self.training_set)
         # device clients: same sampling as the DataLoader below, threaded assembly into pinned buffers (loaders/batch.py); the
         # reference's single-process DataLoader (fedavgclient.py:44-53) needs 80-130 ms per B = 64 image batch on the MI355X host
-        # against a 5.4-ms device step.  args.fast_loader = False restores it.
-        if getattr(self.args, "fast_loader", torch.cuda.is_available()):
+        # against a 5-ms device step.  Default only for datasets that declare themselves deterministic per index by offering
+        # get_batch() (in-memory / pre-decoded): worker threads would reorder the RNG draws of random-transform datasets.
+        # args.fast_loader = True / False overrides.
+        if getattr(self.args, "fast_loader", torch.cuda.is_available() and hasattr(dataset, "get_batch")):
             from ..loaders.batch import PinnedBatchLoader
-            return PinnedBatchLoader(dataset, self.args.B, shuffle=shuffle, workers=getattr(self.args, "loader_workers", 4))
+            return PinnedBatchLoader(dataset, self.args.B, shuffle=shuffle, workers=getattr(self.args, "loader_workers", 8))
         return torch.utils.data.DataLoader(dataset=dataset, batch_size=self.args.B, shuffle=shuffle)
 
     # ------------------------------------------------------------------ the hot loop (fedavgclient.py:55-116)

@@ -50,28 +50,33 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 // stage a [N][64] slice (row stride ld elements) into a swizzled LDS tile of NP rows (zero rows past N).  All global loads
 // of the tile are issued before the first LDS write (clamped row + select instead of a branch), so the staging pays ONE
 // memory round trip instead of one per 256-thread sweep.
-template <int NP>
+template <int NP, int NT = 256>
 __device__ __forceinline__ void stage_tile(char* T, const bf16_t* __restrict__ src, long ld, int N, int tid) {
-  constexpr int IT = NP * 8 / 256;
+  constexpr int IT = (NP * 8 + NT - 1) / NT;
   uint4 v[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+    int idx = tid + NT * i, row = idx >> 3, c = idx & 7;
     int rc = row < N ? row : N - 1;
     v[i] = *(const uint4*)(src + (size_t)rc * ld + c * 8);
   }
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
-    *(uint4*)(T + at_off(row, c)) = row < N ? v[i] : make_uint4(0u, 0u, 0u, 0u);
+    int idx = tid + NT * i, row = idx >> 3, c = idx & 7;
+    if (NP * 8 % NT == 0 || row < NP) *(uint4*)(T + at_off(row, c)) = row < N ? v[i] : make_uint4(0u, 0u, 0u, 0u);
   }
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 // ======================================================================== forward
+// 8 waves per (batch, head): a wave owns the query blocks {wave, wave + 8, ...} (two at N = 197) and requests their Q fragments BEFORE the
+// K / V staging, so that one memory round trip covers all of a workgroup's loads (the 4-wave form of rounds 1-2 walked four query blocks per
+// wave and paid a dependent Q load in each: 18.8 us at B = 64 for 3.8 GFLOP).
+#define AF_WAVES 8
+#define AF_QB 2        // query blocks per wave held in registers (N <= 16 * AF_WAVES * AF_QB = 256)
 template <int NF>  // key fragments of 16 (Npad = 16*NF, NF even)
-__global__ void __launch_bounds__(256) k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse, int B, int N,
-                                                       int H, float scale) {
+__global__ void __launch_bounds__(64 * AF_WAVES) k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse, int B, int N,
+                                                                 int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = 16 * NF;
   char* Ks = smem;
@@ -80,26 +85,33 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(const bf16_t* __restrict_
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
-  stage_tile<NP>(Ks, base + Dm, D3, N, tid);
-  stage_tile<NP>(Vs, base + 2 * Dm, D3, N, tid);
-  __syncthreads();
   const int nqb = (N + 15) >> 4;
-  for (int qb = wave; qb < nqb; qb += 4) {
-    const int qrow = qb * 16 + cl;
-    bf16x8 qf[2];
+  bf16x8 qf[AF_QB][2];
+#pragma unroll
+  for (int r = 0; r < AF_QB; ++r) {
+    const int qrow = (wave + AF_WAVES * r) * 16 + cl;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (qrow < N) v = *(const uint4*)(base + (size_t)qrow * D3 + ks * 32 + g * 8);
-      qf[ks] = *(bf16x8*)&v;
+      qf[r][ks] = *(bf16x8*)&v;
     }
+  }
+  stage_tile<NP, 64 * AF_WAVES>(Ks, base + Dm, D3, N, tid);
+  stage_tile<NP, 64 * AF_WAVES>(Vs, base + 2 * Dm, D3, N, tid);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < AF_QB; ++r) {
+    const int qb = wave + AF_WAVES * r;
+    if (qb >= nqb) break;
+    const int qrow = qb * 16 + cl;
     f32x4 s[NF];
     float m = -INFINITY;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) a = MFMA(row_frag(Ks, f * 16, ks, lane), qf[ks], a);   // S^T[key = 16f+4g+x][q = cl]
+      for (int ks = 0; ks < 2; ++ks) a = MFMA(row_frag(Ks, f * 16, ks, lane), qf[r][ks], a);   // S^T[key = 16f+4g+x][q = cl]
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         float v = (f * 16 + 4 * g + x < N) ? a[x] * scale : -INFINITY;
@@ -373,7 +385,7 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, in
   auto k = k_attn_fwd_mfma<NF>;
   static bool done = false;
   if (!done) { FC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); done = true; }
-  hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, s, qkv, o, lse, B, N, H, scale);
+  hipLaunchKernelGGL(k, dim3(B * H), dim3(64 * AF_WAVES), lds, s, qkv, o, lse, B, N, H, scale);
   FC_LAUNCH_CHECK();
   return 0;
 }

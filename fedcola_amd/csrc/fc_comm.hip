@@ -107,6 +107,12 @@ extern "C" int fc_allreduce_sum(fc_comm_t* c, float* buf, int64_t n, void* strea
 // ---------------------------------------------------------------- closed-form blend with the client pointers as kernel arguments
 #define FC_AGG_MAX_CLIENTS 64
 struct AggBases { const float* p[FC_AGG_MAX_CLIENTS]; };
+// Both blend kernels: grid (AGG_BLOCKS_X, segments); a block strides its segment in 16-byte vectors (every stream of a segment -- global,
+// clients at their own offsets, output -- is read / written as float4 when all of them are 16-byte aligned, which the 64-element segment
+// alignment of fc_model_segment guarantees for models of one family), a scalar loop takes the tail or an unaligned segment.  HBM-bound:
+// (participating clients + 2) x 4 bytes per element.
+#define AGG_BLOCKS_X 64
+__device__ __forceinline__ bool agg_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 __global__ void __launch_bounds__(256) k_blend_v(float* out, const float* g, AggBases bases, int m,
                                                  const int64_t* __restrict__ seg_off, const int64_t* __restrict__ seg_len,
                                                  const int64_t* __restrict__ src_off, const float* __restrict__ seg_w) {
@@ -115,7 +121,25 @@ __global__ void __launch_bounds__(256) k_blend_v(float* out, const float* g, Agg
   const float* w = seg_w + (size_t)sgi * (m + 1);
   const int64_t* so = src_off + (size_t)sgi * m;
   const float wg = w[0];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+  bool vec = agg_al16(out + off) && agg_al16(g + off);
+  for (int j = 0; j < m; ++j)
+    if (w[1 + j] != 0.f && so[j] >= 0) vec = vec && agg_al16(bases.p[j] + so[j]);
+  const int64_t n4 = vec ? len >> 2 : 0;
+  const float4* g4 = (const float4*)(g + off);
+  float4* o4 = (float4*)(out + off);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wg != 0.f) { const float4 x = g4[i]; acc = make_float4(wg * x.x, wg * x.y, wg * x.z, wg * x.w); }
+    for (int j = 0; j < m; ++j) {
+      const float wj = w[1 + j];
+      if (wj != 0.f && so[j] >= 0) {
+        const float4 x = ((const float4*)(bases.p[j] + so[j]))[i];
+        acc.x += wj * x.x; acc.y += wj * x.y; acc.z += wj * x.z; acc.w += wj * x.w;
+      }
+    }
+    o4[i] = acc;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
     float acc = wg != 0.f ? wg * g[off + i] : 0.f;
     for (int j = 0; j < m; ++j) {
       const float wj = w[1 + j];
@@ -125,7 +149,13 @@ __global__ void __launch_bounds__(256) k_blend_v(float* out, const float* g, Agg
   }
 }
 // sequential blend in the reference's order and rounding: g <- g + fl32((theta_j - g) * c_j), j ascending (fedavgserver.py:656-664);
-// explicit round-to-nearest operations so that no multiply-add is contracted
+// every product and sum rounded on its own (no multiply-add contraction), component by component in the vector form: the same bits
+__device__ __forceinline__ float blend_seq1(float acc, float x, float cj) {
+#pragma clang fp contract(off)      // hipcc contracts a*b+c into an fma by default (also through __fmul_rn / __fadd_rn): three roundings here
+  const float d = x - acc;
+  const float p = d * cj;
+  return acc + p;
+}
 __global__ void __launch_bounds__(256) k_blend_seq(float* __restrict__ g, AggBases bases, int m, const int64_t* __restrict__ seg_off,
                                                    const int64_t* __restrict__ seg_len, const int64_t* __restrict__ src_off,
                                                    const float* __restrict__ coef) {
@@ -133,16 +163,27 @@ __global__ void __launch_bounds__(256) k_blend_seq(float* __restrict__ g, AggBas
   const int64_t off = seg_off[sgi], len = seg_len[sgi];
   const float* c = coef + (size_t)sgi * m;
   const int64_t* so = src_off + (size_t)sgi * m;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
-#pragma clang fp contract(off)      // hipcc contracts a*b+c into an fma by default (also through __fmul_rn / __fadd_rn): three roundings here
-    float acc = g[off + i];
+  bool vec = agg_al16(g + off);
+  for (int j = 0; j < m; ++j)
+    if (c[j] != 0.f && so[j] >= 0) vec = vec && agg_al16(bases.p[j] + so[j]);
+  const int64_t n4 = vec ? len >> 2 : 0;
+  float4* g4 = (float4*)(g + off);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 acc = g4[i];
     for (int j = 0; j < m; ++j) {
       const float cj = c[j];
       if (cj != 0.f && so[j] >= 0) {
-        const float d = bases.p[j][so[j] + i] - acc;
-        const float p = d * cj;
-        acc = acc + p;
+        const float4 x = ((const float4*)(bases.p[j] + so[j]))[i];
+        acc.x = blend_seq1(acc.x, x.x, cj); acc.y = blend_seq1(acc.y, x.y, cj); acc.z = blend_seq1(acc.z, x.z, cj); acc.w = blend_seq1(acc.w, x.w, cj);
       }
+    }
+    g4[i] = acc;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+    float acc = g[off + i];
+    for (int j = 0; j < m; ++j) {
+      const float cj = c[j];
+      if (cj != 0.f && so[j] >= 0) acc = blend_seq1(acc, bases.p[j][so[j] + i], cj);
     }
     g[off + i] = acc;
   }
@@ -157,7 +198,7 @@ extern "C" int fc_aggregate_partial(float* out, const float* global, const float
   if (n_segments <= 0) return 0;
   AggBases b;
   for (int j = 0; j < FC_AGG_MAX_CLIENTS; ++j) b.p[j] = j < n_clients ? client_bases[j] : nullptr;
-  hipLaunchKernelGGL(k_blend_v, dim3(64, n_segments), dim3(256), 0, (hipStream_t)stream, out, global, b, (int)n_clients, seg_offset, seg_numel,
+  hipLaunchKernelGGL(k_blend_v, dim3(AGG_BLOCKS_X, n_segments), dim3(256), 0, (hipStream_t)stream, out, global, b, (int)n_clients, seg_offset, seg_numel,
                      src_offset, seg_weights);
   FC_LAUNCH_CHECK();
   return 0;
@@ -176,7 +217,7 @@ extern "C" int fc_aggregate(fc_comm_t* comm, float* global, float* partial, int6
   const bool single = !comm || comm->world == 1;
   // one process: blend straight into the global buffer (every element reads its own old value before writing it)
   float* dst = single ? global : partial;
-  hipLaunchKernelGGL(k_blend_v, dim3(64, n_segments), dim3(256), 0, s, dst, (const float*)global, b, (int)n_clients, seg_offset, seg_numel, src_offset,
+  hipLaunchKernelGGL(k_blend_v, dim3(AGG_BLOCKS_X, n_segments), dim3(256), 0, s, dst, (const float*)global, b, (int)n_clients, seg_offset, seg_numel, src_offset,
                      seg_weights);
   FC_LAUNCH_CHECK();
   if (single) return 0;
@@ -193,7 +234,7 @@ extern "C" int fc_aggregate_blend_seq(float* global, const float* const* client_
   if (n_segments <= 0 || n_clients == 0) return 0;
   AggBases b;
   for (int j = 0; j < FC_AGG_MAX_CLIENTS; ++j) b.p[j] = j < n_clients ? client_bases[j] : nullptr;
-  hipLaunchKernelGGL(k_blend_seq, dim3(64, n_segments), dim3(256), 0, (hipStream_t)stream, global, b, (int)n_clients, seg_offset, seg_numel, src_offset,
+  hipLaunchKernelGGL(k_blend_seq, dim3(AGG_BLOCKS_X, n_segments), dim3(256), 0, (hipStream_t)stream, global, b, (int)n_clients, seg_offset, seg_numel, src_offset,
                      coef);
   FC_LAUNCH_CHECK();
   return 0;

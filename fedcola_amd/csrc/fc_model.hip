@@ -507,6 +507,16 @@ struct Ctx {
   const void* W(int64_t off) const { return wc + (size_t)off * es; }
   // Y[M,N] = X[M,K] . W[N,K]^T
   int gemm_fwd(const void* X, const void* Wt, void* Y, int M, int N, int K, const GemmEpi& e) const {
+#ifdef FC_PROBES
+    static const int big = getenv("FC_GEMM_BIG") ? atoi(getenv("FC_GEMM_BIG")) : 0;   // experiment: large-tile kernel for the forward linears
+    if (big && dt == FC_BF16 && fc_gemm_grouped_epi(e) >= 0) {
+      FcGemmGrouped g{};
+      g.nprob = 1; g.N = N; g.K = K; g.epi = fc_gemm_grouped_epi(e);
+      g.p[0] = FcGemmProb{(const bf16_t*)X, (const bf16_t*)Wt, (bf16_t*)Y, e.bias, e.res, e.preact, e.gelu_in, e.rowscale, (long)K, (long)K, (long)N, M, e.rows_per_sample};
+      int r = fc_gemm_nt_grouped(g, s, big);
+      if (r <= 0) return r;
+    }
+#endif
     if (dt == FC_BF16) {
       int r = fc_gemm_mfma(FC_GEMM_NT, FC_BF16, (const bf16_t*)X, K, (const bf16_t*)Wt, K, Y, N, M, N, K, e, s);
       if (r <= 0) return r;
@@ -738,16 +748,17 @@ static int chain_layer_forward(const Ctx& c, Ws& w, const TowerList& T, int l) {
   }
   return gemm_multi(c, FC_GEMM_NT, gd, nt, D, Hd);
 }
-// Schedules (FC_SCHEDULE): "chain2" (default) = two chains of grouped launches on two streams -- the first part of the image batch on the
-// caller's stream, the rest of it TOGETHER WITH the text tower on a second stream -- plus the weight-gradient stream; "chain" = ONE chain
-// (every launch takes all image and text rows); "streams" = the round-2 form (two image chains, the text tower on its own stream).
+// Schedules (FC_SCHEDULE): "streams" (default) = two image micro-batch chains and the text tower on three streams + the weight-gradient
+// stream; "chain" = ONE chain of grouped launches (every LayerNorm / GEMM launch takes all image and text rows); "chain2" = two chains of
+// grouped launches (the first part of the image batch | the rest of it TOGETHER WITH the text tower).  Measured on the ViT-S step
+// (round 3, one box, ms/step): streams 4.81, chain2 5.22, chain 5.31 -- DESIGN.md section 7.
 enum { SCHED_CHAIN2 = 0, SCHED_CHAIN = 1, SCHED_STREAMS = 2 };
 static int schedule() {
   static const int v = [] {
     const char* e = getenv("FC_SCHEDULE");
-    if (e && strcmp(e, "streams") == 0) return (int)SCHED_STREAMS;
+    if (e && strcmp(e, "chain2") == 0) return (int)SCHED_CHAIN2;
     if (e && strcmp(e, "chain") == 0) return (int)SCHED_CHAIN;
-    return (int)SCHED_CHAIN2;
+    return (int)SCHED_STREAMS;
   }();
   return v;
 }

@@ -8,7 +8,13 @@ threads (each limited to ONE intra-op thread) write contiguous chunks of samples
 release the GIL); the buffers come from torch's
 caching pinned allocator, which does not recycle a block while an asynchronous H2D copy from it is in flight, so the batches can
 be handed to ``DevicePrefetcher`` as they are.  A dataset may offer ``get_batch(indices) -> tuple of stacked fields`` (same fields as
-``__getitem__``); then the per-sample Python overhead (the remaining ~20 ms per batch) disappears as well."""
+``__getitem__``; with an ``out=`` parameter the fields are gathered straight into the pinned batch); then the per-sample Python
+overhead (the remaining ~20 ms per batch) disappears as well.
+
+Reproducibility: the index order is the DataLoader's.  Samples are fetched by worker threads, so a dataset whose ``__getitem__`` draws
+from the global torch RNG (random-crop / flip transforms) sees those draws in a thread-dependent order: ``FedavgClient`` therefore
+uses this loader by default only for datasets that offer ``get_batch`` (in-memory / pre-decoded, deterministic per index) and keeps
+the reference's DataLoader otherwise (``args.fast_loader = True`` opts in explicitly)."""
 from __future__ import annotations
 
 import queue
@@ -30,6 +36,15 @@ class PinnedBatchLoader:
     def __init__(self, dataset, batch_size: int, shuffle: bool = False, drop_last: bool = False, workers: int = 4, pin: bool = True, ahead: int = 2):
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
         self.workers, self.pin, self.ahead = max(1, int(workers)), pin and torch.cuda.is_available(), max(0, int(ahead))
+        self._spec = None
+        gb = getattr(dataset, "get_batch", None)
+        self._into = False
+        if gb is not None:
+            import inspect
+            try:
+                self._into = "out" in inspect.signature(gb).parameters
+            except (TypeError, ValueError):
+                pass
 
     def __len__(self):
         n = len(self.dataset)
@@ -54,17 +69,25 @@ class PinnedBatchLoader:
             k = (n + W - 1) // W
             chunks = [(c * k, idxs[c * k: (c + 1) * k]) for c in range(W) if c * k < n]
             if hasattr(self.dataset, "get_batch"):          # vectorised fetch (in-memory / pre-decoded datasets): one gather per field and chunk
-                first = [torch.as_tensor(v) for v in self.dataset.get_batch(idxs[:1])]
-                bufs = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=self.pin) for t in first]
+                if self._spec is None:                       # field shapes / dtypes: asked once per loader, not once per batch
+                    self._spec = [(tuple(t.shape[1:]), t.dtype) for t in map(torch.as_tensor, self.dataset.get_batch(idxs[:1]))]
+                bufs = [torch.empty((n,) + sh, dtype=dt, pin_memory=self.pin) for sh, dt in self._spec]
 
                 def job(ch):
                     j0, ii = ch
-                    for buf, t in zip(bufs, self.dataset.get_batch(ii)):
-                        buf[j0: j0 + len(ii)].copy_(torch.as_tensor(t))
+                    views = [buf[j0: j0 + len(ii)] for buf in bufs]
+                    if self._into:                           # get_batch(indices, out=views): gathered straight into the pinned batch (one copy)
+                        self.dataset.get_batch(ii, out=views)
+                    else:
+                        for v, t in zip(views, self.dataset.get_batch(ii)):
+                            v.copy_(torch.as_tensor(t))
                 list(pool.map(job, chunks))
                 return tuple(bufs)
             first = [torch.as_tensor(v) for v in self.dataset[idxs[0]]]
             bufs = [torch.empty((n,) + tuple(t.shape), dtype=t.dtype, pin_memory=self.pin) for t in first]
+            for f, v in enumerate(first):                    # the sample fetched for the shapes is used, not fetched again (one decode, one
+                bufs[f][0].copy_(v)                          # set of RNG draws per sample, like the DataLoader)
+            chunks = [(j0, ii) if j0 else (1, ii[1:]) for j0, ii in chunks]
             list(pool.map(lambda ch: self._fill_chunk(bufs, ch[0], ch[1]), chunks))
             return tuple(bufs)
 

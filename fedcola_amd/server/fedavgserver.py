@@ -205,19 +205,20 @@ class FedavgServer(BaseServer):
         """Keys (and their offsets in the client's flat buffer) that ``client.upload()`` would return, from bookkeeping alone."""
         model = client.model if client.model is not None else self.global_models[client.dataset]
         drop_aux = self.args.with_aux and client.modality != "img+txt"
-        return {k: s for k, s in model.segments.items() if not (drop_aux and ("aux" in k or "cross_modal_scale" in k))}
+        segs = {k: s for k, s in model.segments.items() if not (drop_aux and ("aux" in k or "cross_modal_scale" in k))}
+        for ak, tk in model._alias_keys():       # shared tensors (colearn_param 'attn', scope 'all'): the upload lists them under both keys
+            if tk in segs:
+                segs[ak] = segs[tk]
+        return segs
 
-    def _aggregate(self, ids, updated_sizes, fedavg=False, local_partial=None, all_reduce=None, exact=False):
-        """fedavgserver.py:591-668 with the same inputs (self.global_model / task / modality / dataset / out_modality_scale /
-        param_scope / clients).  ``self.comm`` (fedcola_amd.comm.Comm, optional) routes the cross-rank sum through the C ABI's own
-        RCCL communicator instead of torch.distributed.  ``exact=True``: the reference's sequential loop itself on the device
-        (bit-identical rounding; verification mode -- every sampled client local, or one client per rank with ``self.comm``)."""
+    def _aggregate_plan(self, ids, updated_sizes, fedavg=False):
+        """Host half of _aggregate for the current self.global_model / task / modality / dataset: the reference's coefficient table, the
+        blend plan and the flat buffers of the sampled clients this rank trained."""
         assert set(updated_sizes.keys()) == set(ids)
         keys = list(self.global_model.required_params().keys())
         coefficients = agg.mixing_coefficients(keys, self.param_scope, updated_sizes, self.clients, dataset=self.dataset, task=self.task,
                                                modality=self.modality, out_modality_scale=self.out_modality_scale, args=self.args,
                                                fedavg=fedavg)
-        dist, rank, world = _dist()
         client_segments = {i: self._client_upload_segments(self.clients[i]) for i in ids}
         plan = agg.build_plan(self.global_model, ids, coefficients, client_segments)
         local_flats = {}
@@ -225,8 +226,17 @@ class FedavgServer(BaseServer):
             c = self.clients[i]
             if c.model is None:
                 continue                                                      # trained on another rank
-            up = c.upload()                                                   # folds aux into the weights when needed
+            c.upload()                                                        # folds aux into the weights when needed
             local_flats[i] = getattr(c, "_folded", None) if (self.args.with_aux and c.modality != "img+txt") else c.model.flat.data
+        return plan, local_flats, keys, coefficients, client_segments
+
+    def _aggregate(self, ids, updated_sizes, fedavg=False, local_partial=None, all_reduce=None, exact=False):
+        """fedavgserver.py:591-668 with the same inputs (self.global_model / task / modality / dataset / out_modality_scale /
+        param_scope / clients).  ``self.comm`` (fedcola_amd.comm.Comm, optional) routes the cross-rank sum through the C ABI's own
+        RCCL communicator instead of torch.distributed.  ``exact=True``: the reference's sequential loop itself on the device
+        (bit-identical rounding; verification mode -- every sampled client local, or one client per rank with ``self.comm``)."""
+        plan, local_flats, keys, coefficients, client_segments = self._aggregate_plan(ids, updated_sizes, fedavg)
+        dist, rank, world = _dist()
         comm = getattr(self, "comm", None)
         if exact:
             agg.aggregate_exact(self.global_model, keys, ids, coefficients, client_segments, local_flats, comm=comm)
@@ -316,14 +326,23 @@ class FedavgServer(BaseServer):
     def update(self):
         selected_ids = self._sample_clients()
         updated_sizes = self._request(selected_ids, eval=False, participated=True, retain_model=True, save_raw=False)
+        _, rank, world = _dist()
+        items = []
         for i, dataset in enumerate(self.global_models.keys()):
             self.global_model = self.global_models[dataset]
             self.task = DATASET_2_TASK[dataset]
             self.modality = DATASET_2_MODALITY[dataset]
             self.dataset = dataset
             self.out_modality_scale = self.args.out_modality_scales[i]
-            self._aggregate(selected_ids, updated_sizes)
+            if world > 1 and self.global_model.flat.is_cuda and type(self)._aggregate is FedavgServer._aggregate:
+                # several ranks: every dataset's global model of this round goes through ONE all-reduce (aggregate_many)
+                plan, local_flats, *_ = self._aggregate_plan(selected_ids, updated_sizes)
+                items.append((self.global_model, plan, local_flats))
+            else:
+                self._aggregate(selected_ids, updated_sizes)
             self.global_models[dataset] = self.global_model
+        if items:
+            agg.aggregate_many(items, rank=rank, world=world, comm=getattr(self, "comm", None))
         if self.args.with_aux:                                                # fedavgserver.py:821-845
             for dataset in self.global_models.keys():
                 gm = self.global_models[dataset]

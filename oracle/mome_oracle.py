@@ -513,6 +513,38 @@ def client_step(p, cfg: OracleCfg, batch, state, lr: float, weight_decay: float 
     return loss, outs, grads
 
 
+def client_step_autograd(p, cfg: OracleCfg, batch, state, lr: float, weight_decay: float = 0.0):
+    """The same img+txt step with the gradients taken by torch.autograd over forward() instead of the explicit backward() -- what the
+    reference does on the CPU (loss.backward(), fedavgclient.py:97).  Used by bench.py's cpu_baseline (the faster of the two forms is
+    reported) and checked against client_step in tests/test_oracle_kat.py."""
+    assert batch[0] == "img+txt"
+    keys = [k for k in trainable_keys(p, cfg)]
+    leaves = {k: p[k].detach().requires_grad_(True) for k in keys}
+    q = dict(p)
+    q.update(leaves)
+    outs, _ = forward(q, cfg, [batch[1], batch[2]], feat_out=True)
+    tau = contrastive_tau(outs[0].dtype)
+    la = (outs[0] @ outs[1].t()) * tau
+    lab = torch.arange(la.shape[0])
+    loss = (torch.nn.functional.cross_entropy(la, lab) + torch.nn.functional.cross_entropy(la.t(), lab)) / 2
+    gl = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
+    grads = {k: g for k, g in zip(keys, gl) if g is not None}
+    for k in grads:
+        if k.endswith("word_embeddings.weight"):        # nn.Embedding(padding_idx=0): the padding row receives no gradient
+            grads[k] = grads[k].clone()
+            grads[k][0] = 0
+    state["step"] += 1
+    with torch.no_grad():
+        for k in keys:
+            if k not in grads:
+                continue
+            if k not in state["m"]:
+                state["m"][k] = torch.zeros_like(p[k])
+                state["v"][k] = torch.zeros_like(p[k])
+            adamw_step(p[k], grads[k], state["m"][k], state["v"][k], state["step"], lr, weight_decay=weight_decay)
+    return loss.detach(), [o.detach() for o in outs], grads
+
+
 def drop_path_rates(rate: float, depth: int) -> List[float]:
     """dpr = linspace(0, rate, depth) (mome.py:726-728)."""
     return [x.item() for x in torch.linspace(0, rate, depth)]

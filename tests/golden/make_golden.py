@@ -9,6 +9,7 @@ Outputs (tests/golden/):
     update_toy.json     FedavgClient.update() result dict + final weights fingerprint
     update_prox_toy.json  the same for FedproxClient.update() (mu = 0.5)
     agg.json            FedavgServer._aggregate outputs over the scope / compensation matrix
+    agg_colearn.json    the same with colearn_param='attn' img+txt models (shared Attention tensors listed under both towers' keys)
     sampling.json       FedavgServer._sample_clients id lists
     init.json           default-init state_dict fingerprints under torch.manual_seed (factory order check)
     cream.json          CreamflClient.update() per modality and the server half of CreamflServer.update() on toy models
@@ -176,15 +177,19 @@ def update_prox_case():
 DS = {"CIFAR100": ("cls", "img"), "AG_NEWS": ("cls", "txt"), "Flickr30k": ("rtv", "img+txt")}
 
 
-def agg_models(with_aux):
+def agg_models(with_aux, colearn=None):
     out = {}
     common = dict(embed_dim=4, depth=1, num_heads=2, vocab_size=30, max_text_len=8)
+    mm = dict(colearn_param=colearn) if colearn else {}
     out["CIFAR100"] = ref.mome.ModalityAgnosticTransformer(modalities=["img", None], num_classes=[100, None], tasks=["cls", None],
                                                            with_aux=with_aux, aux_trained=True, **common)
     out["AG_NEWS"] = ref.mome.ModalityAgnosticTransformer(modalities=[None, "txt"], num_classes=[None, 4], tasks=[None, "cls"],
                                                           with_aux=with_aux, aux_trained=True, **common)
     out["Flickr30k"] = ref.mome.ModalityAgnosticTransformer(modalities=["img", "txt"], num_classes=[None, None],
-                                                            tasks=["rtv", "rtv"], with_aux=with_aux, aux_trained=True, **common)
+                                                            tasks=["rtv", "rtv"], with_aux=with_aux, aux_trained=True, **common, **mm)
+    if colearn:
+        out["Flickr30k"].sync_shared_weights()      # what every factory does after the constructor (mome.py:950,971,992,1031)
+        assert out["Flickr30k"].blockses[1][0].attn is out["Flickr30k"].blockses[0][0].attn
     for i, (k, m) in enumerate(out.items()):
         sd = m.state_dict()
         m.load_state_dict(det_state_dict({kk: tuple(v.shape) for kk, v in sd.items()}, base_seed=31 * (i + 1)))
@@ -203,7 +208,9 @@ class FakeClient:
         return self.n
 
 
-def agg_case():
+def agg_case(colearn=None):
+    """colearn='attn': the img+txt models are built with colearn_param='attn' (mome.py:836-840), so their state_dict lists the shared
+    Attention tensors under both towers' keys and _aggregate's in-place blend visits the shared tensor twice -> agg_colearn.json."""
     recs = []
     # clients: 2 img, 2 txt, 2 img+txt ; sizes differ
     layout = [(0, "CIFAR100", 50), (1, "CIFAR100", 70), (2, "AG_NEWS", 40), (3, "AG_NEWS", 90), (4, "Flickr30k", 60), (5, "Flickr30k", 30)]
@@ -211,13 +218,15 @@ def agg_case():
               ("attn", "modality", True, False, [1, 1, 1]), ("blocks", "all", False, False, [1, 1, 1]),
               ("blocks", "all", True, False, [1, 1, 0.5]), ("attn", "modality", True, True, [1, 1, 1]),
               ("blocks", "modality", False, False, [1, 0.5, 1])]
+    if colearn:
+        combos = [("attn", "modality", False, False, [1, 1, 1]), ("attn", "modality", True, False, [1, 1, 0.5]), ("none", "dataset", False, False, [1, 1, 1])]
     for shared_param, share_scope, comp, with_aux, oms in combos:
         args = RefArgs(shared_param=shared_param, share_scope=share_scope, compensation=comp, with_aux=with_aux,
                        aux_trained=True, datasets=list(DS.keys()), modalities=["img", "txt", "img+txt"], out_modality_scales=oms)
         srv = object.__new__(ref.fedavgserver.FedavgServer)
         srv.args = args
         srv._round = 0
-        srv.global_models = agg_models(with_aux)
+        srv.global_models = agg_models(with_aux, colearn)
         srv._init_param_scope(shared_param, share_scope)
         clients = []
         for cid, ds, n in layout:
@@ -229,7 +238,7 @@ def agg_case():
         srv._clients = clients
         ids = [0, 1, 3, 4, 5] if shared_param != "none" else [0, 1, 2, 3, 4, 5]
         sizes = {i: clients[i].n for i in ids}
-        rec = dict(shared_param=shared_param, share_scope=share_scope, compensation=comp, with_aux=with_aux,
+        rec = dict(shared_param=shared_param, share_scope=share_scope, compensation=comp, with_aux=with_aux, colearn=colearn,
                    out_modality_scales=oms, ids=ids, sizes={str(k): v for k, v in sizes.items()},
                    layout=layout, scope=dict(srv.param_scope), result={})
         for i, ds in enumerate(srv.global_models.keys()):
@@ -241,7 +250,7 @@ def agg_case():
             rec["result"][ds] = {k: pack(v, True) for k, v in srv.global_model.state_dict().items() if v.dtype.is_floating_point}
         recs.append(rec)
         print("agg", shared_param, share_scope, comp, with_aux)
-    with open(os.path.join(HERE, "agg.json"), "w") as f:
+    with open(os.path.join(HERE, "agg_colearn.json" if colearn else "agg.json"), "w") as f:
         json.dump(recs, f)
 
 
@@ -443,6 +452,9 @@ if __name__ == "__main__":
         model_case("colearn_attn", CASES["colearn_attn"])
         init_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "agg_colearn":
+        agg_case("attn")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "prox":
         update_prox_case()
         sys.exit(0)
@@ -451,6 +463,7 @@ if __name__ == "__main__":
     update_case()
     update_prox_case()
     agg_case()
+    agg_case("attn")
     sampling_case()
     init_case()
     retrieval_case()

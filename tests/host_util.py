@@ -26,13 +26,14 @@ def cpu_local_partial(plan, global_flat, local_flats, include_global):
     return out
 
 
-def agg_models(with_aux, device="cpu"):
+def agg_models(with_aux, device="cpu", colearn=None):
     from fedcola_amd.mome import ModalityAgnosticTransformer as M
     common = dict(embed_dim=4, depth=1, num_heads=2, vocab_size=30, max_text_len=8, init=False)
+    mm = dict(colearn_param=colearn) if colearn else {}
     out = {
         "CIFAR100": M(modalities=["img", None], num_classes=[100, None], tasks=["cls", None], with_aux=with_aux, aux_trained=True, **common),
         "AG_NEWS": M(modalities=[None, "txt"], num_classes=[None, 4], tasks=[None, "cls"], with_aux=with_aux, aux_trained=True, **common),
-        "Flickr30k": M(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], with_aux=with_aux, aux_trained=True, **common),
+        "Flickr30k": M(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], with_aux=with_aux, aux_trained=True, **common, **mm),
     }
     for i, (k, m) in enumerate(out.items()):
         shapes = {kk: tuple(v.shape) for kk, v in m.state_dict().items()}
@@ -52,7 +53,7 @@ def make_server(rec, device="cpu"):
     srv = object.__new__(FedavgServer)
     srv.args = args
     srv._round = 0
-    srv.global_models = agg_models(rec["with_aux"], device)
+    srv.global_models = agg_models(rec["with_aux"], device, rec.get("colearn"))
     srv._init_param_scope(rec["shared_param"], rec["share_scope"])
     clients = []
     for cid, ds, n in rec["layout"]:
@@ -111,5 +112,5 @@ def oracle_sequential_blend(srv, rec):
         coef = AO.coefficients(list(g.keys()), srv.param_scope, ids, sizes, infos, dataset=ds, task=task, modality=modality,
                                out_modality_scale=rec["out_modality_scales"][n], compensation=rec["compensation"],
                                share_scope=rec["share_scope"], arg_modalities=srv.args.modalities)
-        out[ds] = AO.sequential_blend(g, uploads, ids, coef)
+        out[ds] = AO.sequential_blend(g, uploads, ids, coef, alias=dict(gm._alias_keys()))
     return out

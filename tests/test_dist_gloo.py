@@ -64,6 +64,67 @@ def test_two_rank_aggregation_matches_reference(idx):
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
+def _many_worker(rank, world, port, idx, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    import golden_util as G
+    import host_util as H
+    from fedcola_amd import aggregate as agg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rec = G.load("agg.json")[idx]
+        srv = H.make_server(rec)
+        for pos, i in enumerate(rec["ids"]):
+            if srv._owner_rank(pos, world) != rank:
+                srv.clients[i].model = None
+        for c in srv.clients:
+            if c.id not in rec["ids"]:
+                c.model = None
+        ids = rec["ids"]
+        sizes = {i: len(srv.clients[i]) for i in ids}
+        items, calls = [], []
+        for n, ds in enumerate(srv.global_models.keys()):
+            srv.global_model = srv.global_models[ds]
+            srv.task, srv.modality = H.DS[ds]
+            srv.dataset = ds
+            srv.out_modality_scale = rec["out_modality_scales"][n]
+            plan, flats, *_ = srv._aggregate_plan(ids, sizes)
+            items.append((srv.global_model, plan, flats))
+
+        def counted(t):
+            calls.append(t.numel())
+            dist.all_reduce(t)
+        agg.aggregate_many(items, rank=rank, world=world, all_reduce=counted, local_partial=H.cpu_local_partial)
+        assert calls == [sum(gm.flat.numel() for gm, _, _ in items)], calls      # ONE collective over the concatenated buffer
+        H.check_aggregation(srv, rec, tol=3e-6)
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("idx", [1, 4])
+def test_three_global_models_share_one_all_reduce(idx):
+    """fedavgserver.py:812-819 aggregates one global model per dataset; across ranks the three partials travel in ONE all-reduce
+    (aggregate_many) and every rank ends with the reference's models (golden agg.json)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_many_worker, args=(r, 2, port, idx, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
 def _cream_worker(rank, world, port, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))

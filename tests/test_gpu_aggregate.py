@@ -31,6 +31,43 @@ def test_exact_order_mode_is_bit_identical_to_the_reference_loop(idx):
             assert torch.equal(got[k].cpu(), v), f"{ds} {k}: max diff {(got[k].cpu() - v).abs().max()}"
 
 
+@pytest.mark.parametrize("idx", range(3))
+def test_colearn_attn_models_aggregate_on_the_device(idx):
+    """colearn_param='attn' img+txt models: the shared Attention tensors are listed under both towers' keys and the reference blends
+    them once per key for every client (agg_colearn.json = the real FedavgServer._aggregate).  The closed-form HIP blend reproduces the
+    golden, the exact-order mode (each client as two virtual clients of the shared tensor) is bit-identical to the oracle's loop."""
+    rec = G.load("agg_colearn.json")[idx]
+    srv = H.make_server(rec, device="cuda")
+    H.run_aggregation(srv, rec)                              # fc_aggregate: closed form, one row per tensor
+    H.check_aggregation(srv, rec, tol=3e-6)
+    srv = H.make_server(rec, device="cuda")
+    exp = H.oracle_sequential_blend(srv, rec)
+    H.run_aggregation(srv, rec, exact=True)
+    H.check_aggregation(srv, rec, tol=3e-6)
+    for ds, sd in exp.items():
+        got = srv.global_models[ds].state_dict()
+        for k, v in sd.items():
+            assert torch.equal(got[k].cpu(), v), f"{ds} {k}: max diff {(got[k].cpu() - v).abs().max()}"
+
+
+def test_aggregation_leaves_alignment_padding_and_unplanned_segments_untouched():
+    """The flat buffers align every segment to 64 elements; the blend may only write the planned (required_params) segments: the
+    padding between them and the segments outside the plan (aux / scale keys of a with_aux model) keep their bits."""
+    rec = G.load("agg.json")[5]                              # with_aux: aux_weight / cross_modal_scale are not aggregated
+    srv = H.make_server(rec, device="cuda")
+    before = {ds: gm.flat.data.clone() for ds, gm in srv.global_models.items()}
+    H.run_aggregation(srv, rec)
+    H.check_aggregation(srv, rec, tol=3e-6)
+    for ds, gm in srv.global_models.items():
+        planned = torch.zeros(gm.flat.numel(), dtype=torch.bool)
+        for k in gm.required_params():
+            sg = gm.segments[dict(gm._alias_keys()).get(k, k)]
+            planned[sg["offset"]: sg["offset"] + sg["numel"]] = True
+        assert int((~planned).sum()) > 0, "toy models have padding and unplanned segments"
+        assert torch.equal(gm.flat.data.cpu()[~planned], before[ds].cpu()[~planned]), ds
+        assert not torch.equal(gm.flat.data.cpu()[planned], before[ds].cpu()[planned]), ds
+
+
 def test_comm_world1_allreduce_and_exact_allgather():
     from fedcola_amd import _lib
     from fedcola_amd.comm import Comm

@@ -25,14 +25,16 @@ def _run(tmp_path, extra):
 def test_bench_two_ranks_one_device_matches_sequential_blend(tmp_path, agg):
     from oracle import aggregate_oracle as AO
     p, d = _run(tmp_path, ["--agg", agg])
-    if p.returncode != 0 and agg == "cabi" and ("Duplicate GPU" in (p.stdout + p.stderr) or "ncclCommInitRank" in (p.stdout + p.stderr)):
-        pytest.skip("RCCL refuses two ranks on one device; the C-ABI communicator path needs two GPUs")
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 128 and rec["allreduce_bytes"] > 180e6
     assert len(rec["per_rank_ms_per_step"]) == 2 and rec["aggregate_ms"] > 0 and rec["value"] > 0
+    # the line validates itself at N > 1 (the driver's multi-GPU run is the first execution of RCCL with more than one rank)
+    assert rec["rccl_ranks"] == 2 and rec["aggregate_GBps"] > 0 and rec["allreduce_bus_GBps"] > 0
+    assert rec["agg_all_ranks_equal"] is True and rec["agg_slice_recomputed_ok"] is True and rec["agg_checksum_agree"] is True
+    assert rec["agg_paths_agree"] in (None, True)            # None: only one path exists here (RCCL refuses two ranks on one device)
     plan = json.load(open(os.path.join(d, "plan.json")))
     g0 = torch.load(os.path.join(d, "global_before.pt"))
     g1 = torch.load(os.path.join(d, "global_after.pt"))
@@ -46,8 +48,13 @@ def test_bench_two_ranks_one_device_matches_sequential_blend(tmp_path, agg):
     for k, v in exp.items():
         err = float((got[k] - v).abs().max())
         assert err <= 3e-6 * max(1.0, float(v.abs().max())), (k, err)
-    # ranges outside the plan (alignment padding) are untouched
-    assert torch.equal(g1[-1:], g0[-1:]) or True
+    # ranges outside the plan (alignment padding between segments) are untouched
+    planned = torch.zeros(g0.numel(), dtype=torch.bool)
+    for k in plan["keys"]:
+        planned[seg[k][0]: seg[k][0] + seg[k][1]] = True
+    assert torch.equal(g1[~planned], g0[~planned])             # (ViT-S segments are multiples of 64 elements: the toy-model check with real padding is tests/test_gpu_aggregate.py)
+    if agg == "cabi" and not rec["aggregate_path"].startswith("C ABI"):
+        pytest.skip("checked on the torch path: RCCL refuses two ranks on one device, the C-ABI communicator needs two GPUs")
 
 
 def test_bench_gpus_flag_without_enough_devices_fails_loudly(tmp_path):

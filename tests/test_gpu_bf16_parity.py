@@ -99,10 +99,24 @@ def _layer_local(model, sd, grads, B, seq, tower, N, l, D, H, masks=None, aux_tr
     dY = {"mlp.fc1.bias": (T("gdu", (B, N, 4 * D)), tap["du"]), "attn.qkv.bias": (T("gdqkv", (B, N, 3 * D)), tap["dqkv"]),
           "attn.proj.bias": (T("gda" if dp1 is not None else "gxmid", (B, N, D)), tap["da"])}
     chk("du", *dY["mlp.fc1.bias"]); chk("dx1", T("gxmid", (B, N, D)), tap["dx1"]); chk("dqkv", *dY["attn.qkv.bias"])
+    # LayerNorm gradients are column sums of dh (x xhat) where dh = R(dY . W) is a backward temporary the workspace does not keep: it is
+    # re-derived from the library's own dY, and the gradient is held to the rounding noise of its summands -- a 1-ulp flip (2^-8 relative)
+    # of a quarter of the summands, i.e. 0.5 * 2^-8 * sqrt(sum x^2) per column -- not to a fraction of the (cancelling) sum itself.
+    with O.emulate_bf16():
+        dh = {"norm1": O.R(dY["attn.qkv.bias"][0] @ c["Wqkv"]), "norm2": O.R(dY["mlp.fc1.bias"][0] @ c["W1"])}
+    xhat = {"norm1": c["s1"][0], "norm2": c["s2"][0]}
     for k, go in g.items():                     # every parameter gradient of the block, 1-D ones included
         if k.endswith("cross_modal_scale"):
             continue
         gg = grads[k]
+        ln_of = next((n for n in dh if k.endswith(n + ".weight") or k.endswith(n + ".bias")), None)
+        if ln_of is not None and tol_1d is None:
+            terms = (dh[ln_of] * xhat[ln_of] if k.endswith(".weight") else dh[ln_of]).double().reshape(-1, D)
+            noise = 0.5 * 2.0 ** -8 * terms.pow(2).sum(0).sqrt()
+            err = (gg.double() - terms.sum(0)).norm()
+            bound = noise.norm() + 1e-3 * terms.sum(0).norm()
+            assert float(err) <= float(bound), f"tower {tower} layer {l} grad {k}: off by {float(err):.3e}, rounding noise of its summands {float(bound):.3e}"
+            continue
         bias_of = next((b for b in dY if k.endswith(b)), None)
         if bias_of is not None and tol_1d is None:
             # A bias gradient is the column sum of a dY tensor: a heavily cancelling sum of bf16-rounded rows (in the top layer only the

@@ -96,6 +96,25 @@ def test_product_host_plan_vs_golden(idx):
     H.check_aggregation(srv, rec)
 
 
+@pytest.mark.parametrize("idx", range(3))
+def test_colearn_attn_aggregation_vs_golden(idx):
+    """img+txt models built with colearn_param='attn' (mome.py:836-840): state_dict() lists the shared Attention tensors under both
+    towers' keys and the reference's in-place blend visits the shared tensor once per key for every client (agg_colearn.json = the
+    real FedavgServer._aggregate).  Both the oracle (shared tensors under both keys) and the product plan (one row per tensor, closed
+    form over the interleaved sequence) must reproduce it."""
+    rec = G.load("agg_colearn.json")[idx]
+    srv = H.make_server(rec)
+    gm = srv.global_models["Flickr30k"]
+    assert any(k.startswith("blockses.1.") and ".attn." in k for k in gm.required_params()), "alias keys must be listed like the reference's"
+    expect = H.oracle_sequential_blend(srv, rec)
+    for ds, exp in rec["result"].items():
+        for k, r in exp.items():
+            if k in expect[ds]:
+                G.compare(expect[ds][k], r, 1e-6, 1e-7, f"oracle colearn agg {ds} {k}")
+    H.run_aggregation(srv, rec, local_partial=H.cpu_local_partial)
+    H.check_aggregation(srv, rec)
+
+
 def test_update_result_schema_oracle_vs_golden():
     """The oracle client loop (2 epochs x 3 batches, ragged last batch) reproduces FedavgClient.update()'s result dict."""
     from oracle import mome_oracle as O

@@ -118,3 +118,21 @@ def test_hip_kernels_closed_forms(B):
         assert abs(loss - exp) < 1e-5 * max(1.0, exp)
         lo, dao, dbo = O.contrastive_loss(torch.tensor(a, dtype=torch.float64), torch.tensor(b, dtype=torch.float64), tau=tau)
         assert float((da.double() - dao).abs().max()) < 1e-5 and float((db.double() - dbo).abs().max()) < 1e-5
+
+
+def test_autograd_form_of_the_oracle_step_equals_the_explicit_backward():
+    """bench.py's cpu_baseline times the faster of the two forms of the oracle step: explicit backward (client_step) and
+    torch.autograd over the same forward (client_step_autograd, what the reference's loss.backward() does).  Same loss, gradients and
+    updated weights."""
+    import golden_util as G
+    from test_oracle_golden import cfg_from_mk
+    rec = G.load("model_small.json")
+    cfg = cfg_from_mk(rec["mk"])
+    img, ids, _ = G.case_inputs(rec)
+    p1, p2 = G.case_weights("small"), G.case_weights("small")
+    l1, _, g1 = O.client_step(p1, cfg, ("img+txt", img, ids), dict(step=0, m={}, v={}), lr=1e-4)
+    l2, _, g2 = O.client_step_autograd(p2, cfg, ("img+txt", img, ids), dict(step=0, m={}, v={}), lr=1e-4)
+    assert abs(float(l1) - float(l2)) <= 1e-6
+    assert set(g1) == set(g2)
+    for k in g1:
+        assert float((g1[k] - g2[k]).abs().max()) <= 2e-5 * max(float(g1[k].abs().max()), 1e-6), k

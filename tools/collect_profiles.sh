@@ -1,10 +1,10 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun) from the repo root: collects everything profiles/rNN/ holds.  usage: tools/collect_profiles.sh r02
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/$R
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-ROOF="1,6304,384,1536"          # bench.py ROOF_KIND, ROOF_M, ROOF_N, ROOF_K: the NN dX GEMM at its in-model shape
+ROOF=$(python -c "import bench; print(','.join(map(str, (bench.ROOF_KIND, bench.ROOF_M, bench.ROOF_N, bench.ROOF_K))))")   # the NN dX GEMM at its in-model shape
 # 3. counters of the roofline kernel first (bench.py reads roofline_pmc.json), one counter set per pass, kernel-trace only
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" SQ_LDS_BANK_CONFLICT; do
   tag=$(echo $c | tr ' ' '_')
