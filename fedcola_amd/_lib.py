@@ -99,8 +99,6 @@ SIGNATURES = {
     "fc_k_attention_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fc_k_attention_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fc_k_dw": (C.c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "fc_k_gemm_big": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "fc_k_transpose": (C.c_int, [_P, _P, _I, _I, _P]),
     "fc_k_adamw": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "fc_k_cast": (C.c_int, [_I, _P, _P, _L, _P]),
     "fc_retrieval_scratch_bytes": (C.c_size_t, [_I, _I]),

@@ -42,20 +42,44 @@ class Comm:
         return cls.create(box[0], rank, world)
 
     @classmethod
-    def from_file(cls, path: str, rank: int, world: int, timeout: float = 120.0) -> "Comm":
+    def from_file(cls, path: str, rank: int, world: int, timeout: float = 120.0, nonce: str = None) -> "Comm":
+        """Rendezvous through a shared file.  The file starts with a job nonce (``nonce``, default $FC_JOB_NONCE or
+        MASTER_ADDR:MASTER_PORT of the launcher) so that a file left over by an earlier or crashed job is never taken for this job's
+        id; rank 0 removes any old file first and deletes its own once every rank has joined (ncclCommInitRank is collective)."""
+        import hashlib
+        if nonce is None:
+            nonce = os.environ.get("FC_JOB_NONCE") or f'{os.environ.get("MASTER_ADDR", "")}:{os.environ.get("MASTER_PORT", "")}'
+        tag = hashlib.sha256(nonce.encode()).digest()[:16]
         if rank == 0:
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
             tmp = path + ".tmp"
             with open(tmp, "wb") as f:
-                f.write(cls.unique_id())
+                f.write(tag + cls.unique_id())
             os.replace(tmp, path)
         t0 = time.time()
-        while not os.path.exists(path):
+        uid = None
+        while uid is None:
+            try:
+                with open(path, "rb") as f:
+                    blob = f.read()
+                if len(blob) == 16 + ID_BYTES and blob[:16] == tag:
+                    uid = blob[16:]
+                    break
+            except FileNotFoundError:
+                pass
             if time.time() - t0 > timeout:
-                raise TimeoutError(f"no RCCL id at {path}")
+                raise TimeoutError(f"no RCCL id of this job at {path}")
             time.sleep(0.01)
-        with open(path, "rb") as f:
-            uid = f.read()
-        return cls.create(uid, rank, world)
+        comm = cls.create(uid, rank, world)
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
+        return comm
 
     def all_reduce(self, t):
         import torch

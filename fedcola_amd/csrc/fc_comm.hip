@@ -6,6 +6,8 @@
 // library loads on a machine without RCCL and a caller that never aggregates across processes never touches it.  A process
 // is one rank = one GPU; xGMI is RCCL's business.
 #include <dlfcn.h>
+
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 
@@ -25,11 +27,14 @@ struct RcclApi {
   int (*AllGather)(const void*, void*, size_t, int, fc_nccl_comm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
+static void rccl_load(RcclApi& api);
 static RcclApi* rccl() {
   static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.so ? &api : nullptr;
-  tried = true;
+  static std::once_flag once;                       // two threads may create communicators at the same time
+  std::call_once(once, [] { rccl_load(api); });
+  return api.so ? &api : nullptr;
+}
+static void rccl_load(RcclApi& api) {
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* so = nullptr;
   for (const char* n : names) {                     // already mapped (e.g. by torch)?  use that copy
@@ -37,7 +42,7 @@ static RcclApi* rccl() {
     if (so) break;
   }
   for (size_t i = 0; !so && i < sizeof(names) / sizeof(names[0]); ++i) so = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-  if (!so) return nullptr;
+  if (!so) return;
 #define FC_SYM(field, name) *(void**)(&api.field) = dlsym(so, name)
   FC_SYM(GetUniqueId, "ncclGetUniqueId");
   FC_SYM(CommInitRank, "ncclCommInitRank");
@@ -46,9 +51,8 @@ static RcclApi* rccl() {
   FC_SYM(AllGather, "ncclAllGather");
   FC_SYM(GetErrorString, "ncclGetErrorString");
 #undef FC_SYM
-  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) return nullptr;
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) return;
   api.so = so;
-  return &api;
 }
 #define FC_CHECK_NCCL(expr)                                                                                  \
   do {                                                                                                       \

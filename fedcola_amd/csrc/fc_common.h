@@ -41,6 +41,15 @@ static inline bool fc_ablated(const char* what) {
 #else
 #define FC_ABLATED(what) false
 #endif
+// Tuning and experiment knobs (FC_MB_FIRST, FC_DW_FLUSH, FC_SCHEDULE, FC_FUSED_OPT, ...) exist only in the tools build: the product library
+// reads no FC_* environment variable and always runs the defaults.
+#ifdef FC_PROBES
+static inline int fc_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline const char* fc_knob_str(const char* name) { return getenv(name); }
+#else
+static inline int fc_knob(const char*, int dflt) { return dflt; }
+static inline const char* fc_knob_str(const char*) { return nullptr; }
+#endif
 #define FC_TRY(expr)          \
   do {                        \
     int _r = (expr);          \

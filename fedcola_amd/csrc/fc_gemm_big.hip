@@ -20,6 +20,7 @@
 // 16-byte output chunks (rows of 192 B / 96 B per wave), applies bias / GELU / residual / drop-path scale in fp32 and stores bf16.  No
 // workgroup barrier inside the epilogue.  Every global input of the epilogue is requested before the tile's last k-step; stores use
 // out-of-range offsets for masked lanes so that every wave issues the same number and the main loop's waits are counted.
+#ifdef FC_PROBES   // FC_PROBES: whole file -- an experiment kept in the tools build only (large-tile grouped NT GEMM); the product library does not contain it
 #include <stdlib.h>
 #include <string.h>
 
@@ -427,3 +428,5 @@ extern "C" int fc_k_transpose(const void* src, void* dst, int32_t out, int32_t i
   FC_CHECK_HIP(hipFree(dev));
   return r;
 }
+
+#endif  // FC_PROBES

@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
 }
 
 int fc_gemm_dw_wide_supported(const FcTnProblem& p) {
-  static const int on = getenv("FC_DW_WIDE") ? atoi(getenv("FC_DW_WIDE")) : 1;
+  static const int on = fc_knob("FC_DW_WIDE", 1);
   if (!on) return 0;
   // in (N) a multiple of the 384-wide tile: every linear of the ViT-S / ViT-B shaped models (384, 768, 1536, 3072)
   return (p.N % DW_BN) == 0 && !((p.M & 7) || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) ||
@@ -494,7 +494,7 @@ int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hi
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
   }
-  static const int form_env = getenv("FC_DW_WIDE") ? atoi(getenv("FC_DW_WIDE")) : 2;      // 1: 8 waves, 2: 8 consumer + 2 loader waves
+  static const int form_env = fc_knob("FC_DW_WIDE", 2);      // 1: 8 waves, 2: 8 consumer + 2 loader waves
   const int form = form_arg ? form_arg : form_env;
   if (form == 2) {
     static bool done2 = false;

@@ -20,6 +20,7 @@
 // (bias, GELU, residual) fills issue slots between the MFMAs instead of idling the matrix pipe.  A half goes through a private
 // 2-KB LDS region: the residual / GELU' operand rows arrive there by LDS-DMA (so every vector-memory operation of the kernel
 // is a DMA or a store, and all waits are counted by hand), the results are written back packed and leave as whole 128-B rows.
+#ifdef FC_PROBES   // FC_PROBES: whole file -- an experiment kept in the tools build only (weight-stationary K = 384 GEMM); the product library does not contain it
 #include <stdlib.h>
 #include <string.h>
 
@@ -478,3 +479,5 @@ int fc_gemm_ws(int kind, const bf16_t* A, long lda, const bf16_t* Wt, long ldw, 
 #undef GO
   return 1;
 }
+
+#endif  // FC_PROBES

@@ -37,6 +37,7 @@ class PinnedBatchLoader:
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
         self.workers, self.pin, self.ahead = max(1, int(workers)), pin and torch.cuda.is_available(), max(0, int(ahead))
         self._spec = None
+        self._pool = None
         gb = getattr(dataset, "get_batch", None)
         self._into = False
         if gb is not None:
@@ -45,6 +46,24 @@ class PinnedBatchLoader:
                 self._into = "out" in inspect.signature(gb).parameters
             except (TypeError, ValueError):
                 pass
+
+    def _get_pool(self):
+        # one pool for the loader's lifetime: starting 8 threads and running torch.set_num_threads(1) in each costs 2-3 ms, which
+        # an epoch of 20 steps (100 ms) pays again at every iteration otherwise
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(self.workers, initializer=_worker_init)
+            list(self._pool.map(lambda _: None, range(self.workers)))      # start the threads now
+        return self._pool
+
+    def __getstate__(self):              # copies / pickles of a loader (deep-copied clients) start without the pool
+        d = dict(self.__dict__)
+        d["_pool"] = None
+        return d
+
+    def __del__(self):
+        pool = getattr(self, "_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=False)
 
     def __len__(self):
         n = len(self.dataset)
@@ -91,10 +110,10 @@ class PinnedBatchLoader:
             list(pool.map(lambda ch: self._fill_chunk(bufs, ch[0], ch[1]), chunks))
             return tuple(bufs)
 
+        pool = self._get_pool()
         if self.ahead == 0:
-            with ThreadPoolExecutor(W, initializer=_worker_init) as pool:
-                for idxs in batches:
-                    yield assemble(pool, idxs)
+            for idxs in batches:
+                yield assemble(pool, idxs)
             return
         # a producer thread assembles `ahead` batches in advance, under the consumer's device work
         q: "queue.Queue" = queue.Queue(maxsize=self.ahead)
@@ -102,11 +121,10 @@ class PinnedBatchLoader:
 
         def produce():
             try:
-                with ThreadPoolExecutor(W, initializer=_worker_init) as pool:
-                    for idxs in batches:
-                        if stop.is_set():
-                            return
-                        q.put(assemble(pool, idxs))
+                for idxs in batches:
+                    if stop.is_set():
+                        return
+                    q.put(assemble(pool, idxs))
                 q.put(None)
             except BaseException as e:      # surfaces in the consumer
                 q.put(e)

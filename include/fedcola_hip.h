@@ -26,8 +26,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 4   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw;
-                              4: fc_k_gemm_big, fc_k_transpose, fc_compute_weights_bytes covers the transposed copy */
+#define FC_ABI_VERSION 3   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw */
 
 enum { FC_PREC_FP32 = 0, FC_PREC_BF16 = 1 };
 enum { FC_TASK_NONE = 0, FC_TASK_CLS = 1, FC_TASK_RTV = 2 };
@@ -261,14 +260,6 @@ int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, const void* o,
  * operands), db[out] = column sums of dY (may be NULL).  wide: 0 = 128x128 tiles; 1 / 2 = 128x384 tiles (need in % 384 == 0), 8 waves / 8 consumer + 2 LDS-DMA loader waves.
  * Test entry point: allocates its one-entry problem table and synchronises the stream. */
 int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, float* db, int32_t rows, int32_t out, int32_t in, void* stream);
-/* large-tile grouped NT GEMM (csrc/fc_gemm_big.hip): C_p[M_p,N] = A_p[M_p,K] . W_p[N,K]^T for one or two row sets (A1 == NULL: one).
- * epi: 0 plain, 1 +bias, 2 +bias +residual(in), 3 (+bias)*rowscale +residual(in), 4 gelu(+bias) -> C and gelu' -> out2, 5 * in.
- * force_bm: 0 heuristic, 128 / 256 tile rows.  Returns 1 when the shape is not covered (K % 64, N % 8, alignment). */
-int fc_k_gemm_big(const void* A0, const void* W0, void* C0, int32_t M0, const void* A1, const void* W1, void* C1, int32_t M1, int32_t N,
-                  int32_t K, int32_t epi, const float* bias0, const float* bias1, const void* in0, const void* in1, void* out2_0,
-                  void* out2_1, const float* rowscale0, const float* rowscale1, int32_t rows_per_sample, int32_t force_bm, void* stream);
-/* dst[in][out] = src[out][in], bf16 (the transposed compute-weight copy the dX products read) */
-int fc_k_transpose(const void* src, void* dst, int32_t out, int32_t in, void* stream);
 int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
                int32_t step, void* stream);
 int fc_k_cast(int32_t dt_out, const float* src, void* dst, int64_t n, void* stream);

@@ -182,7 +182,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fedcola_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.fc_abi_version() == 4
+    assert lib.fc_abi_version() == 3
 
 
 def test_model_layout_and_errors_without_gpu():
@@ -210,7 +210,7 @@ def test_header_is_plain_c(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     src = tmp_path / "t.c"
-    src.write_text('#include "fedcola_hip.h"\nint main(void) { fc_model_cfg c; (void)c; return FC_ABI_VERSION == 4 ? 0 : 1; }\n')
+    src.write_text('#include "fedcola_hip.h"\nint main(void) { fc_model_cfg c; (void)c; return FC_ABI_VERSION == 3 ? 0 : 1; }\n')
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -329,3 +329,36 @@ def test_algorithm_plugin_fedavg_optimizer_is_fedavg():
         opt.zero_grad()
         opt.step()                                                      # nothing pending: no change
         assert float((server["a.bias"] - sum(c["a.bias"] * n for c, n in zip(clients, sizes)) / sum(sizes)).abs().max()) < 1e-6
+
+
+def test_fc_model_cfg_fields_agree_between_header_binding_and_integration_doc():
+    """The C struct (include/fedcola_hip.h), the ctypes mirror (fedcola_amd/_lib.py) and the snippet a reference maintainer would copy
+     must list the same fields in the same order: a binding made from a stale copy passes a short struct
+    (the doc lacked colearn_attn)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "fedcola_hip.h")).read()
+    body = re.search(r"typedef struct fc_model_cfg \{(.*?)\} fc_model_cfg;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        assert decl.startswith("int32_t "), decl
+        c_fields += [f.strip() for f in decl[len("int32_t "):].split(",")]
+    from fedcola_amd import _lib
+    py_fields = [n for n, t in _lib.FcModelCfg._fields_]
+    assert py_fields == c_fields
+    import ctypes as C
+    assert C.sizeof(_lib.FcModelCfg) == 4 * len(c_fields)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    snip = re.search(r"class FcModelCfg\(C\.Structure\):.*?_fields_ = \[\(n, C\.c_int32\) for n in \((.*?)\)\]", doc, re.S).group(1)
+    doc_fields = re.findall(r'"(\w+)"', snip)
+    assert doc_fields == c_fields
+    # the same for fc_segment
+    seg = re.search(r"typedef struct fc_segment \{(.*?)\} fc_segment;", hdr, re.S).group(1)
+    seg = re.sub(r"/\*.*?\*/", "", seg, flags=re.S)
+    seg_fields = [re.split(r"[\s\[]", d.strip().split()[-1])[0] for d in seg.split(";") if d.strip()]
+    assert [n for n, t in _lib.FcSegment._fields_] == seg_fields

@@ -5,8 +5,12 @@ device-side durations.   usage: tools/gemm_big_bench.py [reps] [check]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ["FC_PROBES_LIB"] = "1"        # the large-tile kernel is an experiment of the tools build (python -m fedcola_amd.build --probes)
 from fedcola_amd import _lib
 L = _lib.lib(); P = _lib.ptr
+_P, _I = C.c_void_p, C.c_int32
+L.fc_k_gemm_big.restype = C.c_int
+L.fc_k_gemm_big.argtypes = [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 check = len(sys.argv) > 2
 sp = _lib.stream_ptr()

@@ -66,4 +66,4 @@ if torch.cuda.is_available():
                 torch.cuda.synchronize(); t0 = time.perf_counter(); k0 = k
         torch.cuda.synchronize()
         e2e[name] = round((time.perf_counter() - t0) / (k - k0) * 1e3, 2)
-    print(json.dumps(dict(client_loop_ms_per_step=e2e, note="ViT-S bf16 fused step fed from host memory; device step alone ~5.5 ms")))
+    print(json.dumps(dict(client_loop_ms_per_step=e2e, note="ViT-S bf16 fused step fed from host memory; the device step alone is bench.py's ms_per_step (4.8 ms in round 3)")))

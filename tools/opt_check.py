@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Fused-optimizer check (development aid + tests/test_gpu_model.py): one bf16 client step with FC_FUSED_OPT from the env; saves the
-parameters, both moments, the bf16 compute weights and the last gradients.  usage: opt_check.py img+txt|img OUT.pt"""
+parameters, both moments, the bf16 compute weights and the last gradients.  usage: opt_check.py img+txt|img OUT.pt [width=128]
+width 128: every layer linear takes the 128x128-tile grouped kernel; width 384 (depth 2, B = 16: two micro-batch chains): the wide
+128x384-tile kernels the ViT-S / ViT-B steps use (FC_DW_WIDE = 1 | 2 selects their two forms)."""
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
@@ -9,14 +11,16 @@ import product_util as PU
 from synth import det_state_dict
 from fedcola_amd.mome import ModalityAgnosticTransformer as M
 kind = sys.argv[1]
-common = dict(embed_dim=128, depth=5, num_heads=2, vocab_size=64, max_text_len=16)
+width = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+common = dict(embed_dim=128, depth=5, num_heads=2, vocab_size=64, max_text_len=16) if width == 128 else \
+    dict(embed_dim=width, depth=2, num_heads=width // 64, vocab_size=64, max_text_len=16)
 if kind == "img+txt":
     mk = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], **common)
 else:
     mk = dict(modalities=["img", None], num_classes=[10, None], tasks=["cls", None], **common)
 torch.manual_seed(0)
 sd = det_state_dict({k: tuple(v.shape) for k, v in M(**mk).state_dict().items()}, base_seed=5)
-B = 12
+B = 12 if width == 128 else 16
 g = torch.Generator().manual_seed(3)
 img = (torch.randn(B, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1)
 ids = torch.randint(1, 64, (B, 16), generator=g)
