@@ -1244,7 +1244,7 @@ struct DwState {
 };
 // launch the problems queued since the last flush as one grouped GEMM on the dW stream, ordered after everything enqueued so
 // far on this tower's stream (their dY / X operands are complete by then)
-static int flush_dw(const Ctx& c) {
+static int flush_dw(const Ctx& c, bool narrow = false) {      // narrow: 128x128 tiles for every problem (a short last chunk)
   if (!c.defer || !c.dw) return 0;
   std::vector<FcTnProblem>& all = *c.defer;
   DwState& st = *c.dw;
@@ -1253,8 +1253,8 @@ static int flush_dw(const Ctx& c) {
   FC_REQUIRE((int)all.size() <= st.max_probs, "internal: too many deferred weight-gradient problems");
   // problems whose `in` is a multiple of 384 take the 128x384-tile kernel, the rest the 128x128 one: two launches over two
   // contiguous parts of the table, each with its own tile numbering
-  const size_t nw = (size_t)(std::stable_partition(all.begin() + beg, all.end(), [](const FcTnProblem& p) { return fc_gemm_dw_wide_supported(p) != 0; }) -
-                             (all.begin() + beg));
+  const size_t nw = narrow ? 0 : (size_t)(std::stable_partition(all.begin() + beg, all.end(), [](const FcTnProblem& p) { return fc_gemm_dw_wide_supported(p) != 0; }) -
+                                          (all.begin() + beg));
   int tiles_w = 0, tiles = 0;
   for (size_t i = beg; i < beg + nw; ++i) {
     all[i].tile_start = tiles_w;
@@ -1665,7 +1665,12 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
         }
         late->pending = true;
       }
-      FC_TRY(flush_dw(cf_));
+      // The last chunk is the only weight-gradient work nothing overlaps.  Making it shorter (FC_DW_FLUSH_AT = 6,2 / 6,1 / 7,3 / 6,3) and / or
+      // narrow-tiled (more, smaller tiles) measured SLOWER every time (tools build, same box, ms per step: default 4.68-4.73, "6,2" 4.79-4.81,
+      // "6,2" narrow 4.77-4.78, "6,1" narrow 4.81, "7,3" narrow 4.80, narrow alone 4.91; profiles/r03/dw_tail_ab.txt): the extra middle
+      // chunk competes with the chains for CUs and costs more than the shorter tail returns.
+      static const bool last_narrow = fc_knob("FC_DW_LAST_NARROW", 0) != 0;
+      FC_TRY(flush_dw(cf_, last_narrow));
     }
     FC_STREAM_EV(3, m->side); FC_STREAM_EV(4, m->mbs[0]); FC_STREAM_EV(5, s);
     FC_TRY(chains_join(s, ch, n));
