@@ -1116,8 +1116,12 @@ static int build_chains(const fc_model* m, const Ws& w, hipStream_t s, bool fwd,
     if (fwd && nimg == 2 && fwd_chains == 3 && B >= 24 && m->dws) nimg = 3;   // 4.79 -> 4.71 ms per ViT-S step (round 3)
     hipStream_t st[3] = {s, m->mbs[0], m->dws};
     hipEvent_t ev[3] = {nullptr, m->ev_mb_join[0], m->ev_dw_prev};
+    // cut points of the three forward chains in percent of the batch (FC_FWD_CUTS = "a,b", tools build; default thirds)
+    static const int cut_a = [] { const char* e = fc_knob_str("FC_FWD_CUTS"); return e ? atoi(e) : 0; }();
+    static const int cut_b = [] { const char* e = fc_knob_str("FC_FWD_CUTS"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
+    auto cut3 = [&](int k) { return k <= 0 ? 0 : k >= 3 ? B : (cut_a > 0 && cut_b > cut_a && cut_b < 100) ? std::max(k, std::min(B - 3 + k, (B * (k == 1 ? cut_a : cut_b) + 50) / 100)) : B * k / 3; };
     for (int k = 0; k < nimg; ++k) {
-      const int b0 = nimg == 3 ? B * k / 3 : mb_begin(B, k, nimg), b1 = nimg == 3 ? B * (k + 1) / 3 : mb_begin(B, k + 1, nimg);
+      const int b0 = nimg == 3 ? cut3(k) : mb_begin(B, k, nimg), b1 = nimg == 3 ? cut3(k + 1) : mb_begin(B, k + 1, nimg);
       ch[n++] = ChainDef{st[k], nimg == 1 ? w : slice_ws(m, w, 0, b0, b1 - b0, k < 2 ? k : 1, false), 0, b0, ev[k]};
     }
   }
