@@ -647,6 +647,11 @@ static int launch_gemm_epi(const GemmGroup& g, hipStream_t s) {
     max_wg = 2 * cus;   // 64 KB of LDS per workgroup: two per CU
   }
   int grid = g.ntiles < max_wg ? g.ntiles : max_wg;
+  // FC_GEMM_TPW (tools build): at least this many tiles per workgroup, so that a workgroup's epilogue runs under its next tile's loads
+  // even when the launch has fewer tiles than the chip has slots; FC_GEMM_MAXWG caps the grid
+  static const int tpw = fc_knob("FC_GEMM_TPW", 1), cap = fc_knob("FC_GEMM_MAXWG", 0);
+  if (tpw > 1 && grid > (g.ntiles + tpw - 1) / tpw) grid = (g.ntiles + tpw - 1) / tpw;
+  if (cap > 0 && grid > cap) grid = cap;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, g);
   FC_LAUNCH_CHECK();
   return 0;

@@ -25,13 +25,15 @@ client._BaseClient__identifier = 0
 client.dataset = "Flickr30k"
 gmodel = copy.deepcopy(model)
 stamps = []
+evs = []
 L = _lib.lib()
 orig_step = L.fc_client_step
 
 
 class Wrap:      # records when each step is handed to the library and when the call returns
     def __call__(self, *args):
-        t0 = time.perf_counter(); r = orig_step(*args); stamps.append(("step", t0, time.perf_counter())); return r
+        t0 = time.perf_counter(); r = orig_step(*args); ev = torch.cuda.Event(enable_timing=True); ev.record(); evs.append(ev)
+        stamps.append(("step", t0, time.perf_counter())); return r
 L.fc_client_step = Wrap()
 orig_iter = PF.DevicePrefetcher.__iter__
 
@@ -41,8 +43,8 @@ def traced_iter(self):
         stamps.append(("batch", time.perf_counter(), 0)); yield b
 PF.DevicePrefetcher.__iter__ = traced_iter
 for r in range(4):
-    del stamps[:]
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    del stamps[:]; del evs[:]
+    torch.cuda.synchronize(); ev0 = torch.cuda.Event(enable_timing=True); ev0.record(); t0 = time.perf_counter()
     client.download({"Flickr30k": gmodel}); t1 = time.perf_counter()
     res = client.update(); t2 = time.perf_counter()
     torch.cuda.synchronize(); t3 = time.perf_counter()
@@ -51,4 +53,5 @@ for r in range(4):
         print(json.dumps(dict(round=r, download_ms=round((t1 - t0) * 1e3, 2), update_ms=round((t2 - t1) * 1e3, 2),
                               first_batch_at_ms=round((batches[0][1] - t1) * 1e3, 2), first_step_call_ms=round((steps[0][2] - steps[0][1]) * 1e3, 2),
                               second_step_call_ms=round((steps[1][2] - steps[1][1]) * 1e3, 2), median_step_call_ms=round(sorted(s[2] - s[1] for s in steps)[len(steps) // 2] * 1e3, 2),
-                              last_step_returned_at_ms=round((steps[-1][2] - t1) * 1e3, 2), batch_gaps_ms=[round((batches[i + 1][1] - batches[i][1]) * 1e3, 1) for i in range(len(batches) - 1)])))
+                              last_step_returned_at_ms=round((steps[-1][2] - t1) * 1e3, 2), device_step_end_ms_after_round_start=[round(ev0.elapsed_time(e), 1) for e in evs],
+                              device_step_ms=[round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(len(evs) - 1)], batch_gaps_ms=[round((batches[i + 1][1] - batches[i][1]) * 1e3, 1) for i in range(len(batches) - 1)])))
