@@ -107,16 +107,21 @@ __global__ void __launch_bounds__(64 * AF_WAVES) k_attn_fwd_mfma(const bf16_t* _
     const int qrow = qb * 16 + cl;
     f32x4 s[NF];
     float m = -INFINITY;
+    // key blocks past N (block 13 of 14 at N = 197) are skipped, and only the block that straddles N pays the mask: both tests are
+    // wave-uniform (scalar branches)
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      f32x4 a = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (f * 16 < N) {
+        a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) a = MFMA(row_frag(Ks, f * 16, ks, lane), qf[r][ks], a);   // S^T[key = 16f+4g+x][q = cl]
+        for (int ks = 0; ks < 2; ++ks) a = MFMA(row_frag(Ks, f * 16, ks, lane), qf[r][ks], a);   // S^T[key = 16f+4g+x][q = cl]
+        if (f * 16 + 16 > N) {
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        float v = (f * 16 + 4 * g + x < N) ? a[x] : -INFINITY;   // raw scores: the scale rides in the exponent's fma below
-        a[x] = v;
-        m = fmaxf(m, v);
+          for (int x = 0; x < 4; ++x) a[x] = (f * 16 + 4 * g + x < N) ? a[x] : -INFINITY;   // raw scores: the scale rides in the exponent's fma below
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) m = fmaxf(m, a[x]);
       }
       s[f] = a;
     }
@@ -125,9 +130,14 @@ __global__ void __launch_bounds__(64 * AF_WAVES) k_attn_fwd_mfma(const bf16_t* _
     float sum = 0.f;
     const float sc2 = scale * 1.4426950408889634f, m2 = m * sc2;                    // exp(scale (s - m)) = 2^(s sc2 - m sc2): one fma + v_exp_f32 per score
 #pragma unroll
-    for (int f = 0; f < NF; ++f)
+    for (int f = 0; f < NF; ++f) {
+      if (f * 16 < N) {
 #pragma unroll
-      for (int x = 0; x < 4; ++x) { float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][x], sc2, -m2)); s[f][x] = p; sum += p; }
+        for (int x = 0; x < 4; ++x) { float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][x], sc2, -m2)); s[f][x] = p; sum += p; }
+      } else {
+        s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     f32x4 oacc[4];
@@ -135,6 +145,7 @@ __global__ void __launch_bounds__(64 * AF_WAVES) k_attn_fwd_mfma(const bf16_t* _
     for (int db = 0; db < 4; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ss = 0; ss < NF / 2; ++ss) {
+      if (ss * 32 >= N) break;
       bf16x8 pb = pack8(s[2 * ss], s[2 * ss + 1]);                      // P^T[key(8g+j)][q = cl]
 #pragma unroll
       for (int db = 0; db < 4; ++db) oacc[db] = MFMA(tr_frag(Vs, 32 * ss, db * 16, lane), pb, oacc[db]);   // O^T[d = 16db+4g+x][q]
@@ -172,7 +183,7 @@ __device__ __forceinline__ float dot8(const bf16x8& a, const bf16x8& b) {
 // Register blocking: a wave works on a PAIR of 16-row blocks (32 queries in the dQ body, 32 keys in the dK/dV body) at a time, so
 // every K / V (Q / dO) fragment read from LDS feeds two MFMAs instead of one: half the LDS reads per MFMA of the one-block form
 // (the LDS port, not the matrix pipe, bounded that form), and twice the independent MFMA chains per step to cover their latency.
-template <int NF>
+template <int NF, int U, int NW>
 __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N,
                                                  int H, float scale) {
@@ -180,23 +191,24 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
   char* Ks = smem;
   char* Vs = smem + NP * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
+  const float sc2 = scale * 1.4426950408889634f;   // exp(scale s - lse) = 2^(s sc2 - lse log2 e)
   const int b = bh / H, h = bh % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
   const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
   const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
-  stage_tile<NP>(Ks, base + Dm, D3, N, tid);
-  stage_tile<NP>(Vs, base + 2 * Dm, D3, N, tid);
+  stage_tile<NP, 64 * NW>(Ks, base + Dm, D3, N, tid);
+  stage_tile<NP, 64 * NW>(Vs, base + 2 * Dm, D3, N, tid);
   __syncthreads();
   bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
-  for (int qp = wave; qp < NF / 2; qp += 4) {             // query pair: rows 32 qp .. 32 qp + 31
-    if (qp * 32 >= N) break;
-    bf16x8 qf[2][2], dof[2][2];
-    float dl[2], lq[2];
-    int qrow[2];
+  for (int qp = wave; qp < NF / U; qp += NW) {           // query group: rows 16 U qp .. 16 U (qp + 1) - 1
+    if (qp * 16 * U >= N) break;
+    bf16x8 qf[U][2], dof[U][2];
+    float dl[U], lq[U];
+    int qrow[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      qrow[u] = (2 * qp + u) * 16 + cl;
+    for (int u = 0; u < U; ++u) {
+      qrow[u] = (U * qp + u) * 16 + cl;
       float acc = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -207,11 +219,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
       acc += __shfl_xor(acc, 16, 64);
       acc += __shfl_xor(acc, 32, 64);                                    // delta[q = cl]
       dl[u] = acc;
-      lq[u] = qrow[u] < N ? lse[((size_t)b * H + h) * N + qrow[u]] : 1e30f;
+      lq[u] = qrow[u] < N ? lse[((size_t)b * H + h) * N + qrow[u]] * 1.4426950408889634f : 1e30f;   // log2 units, like sc2
     }
-    f32x4 dq[2][4];
+    f32x4 dq[U][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int db = 0; db < 4; ++db) dq[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -221,9 +233,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
       for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { kf[hh][ks] = row_frag(Ks, (2 * ss + hh) * 16, ks, lane); vf[hh][ks] = row_frag(Vs, (2 * ss + hh) * 16, ks, lane); }
-      bf16x8 bfg[2];
+      bf16x8 bfg[U];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < U; ++u) {
         f32x4 ds[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -234,7 +246,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
             dpt = MFMA(vf[hh][ks], dof[u][ks], dpt);       // dP^T[key][q]
           }
 #pragma unroll
-          for (int x = 0; x < 4; ++x) ds[hh][x] = __expf(st[x] * scale - lq[u]) * (dpt[x] - dl[u]);
+          for (int x = 0; x < 4; ++x) ds[hh][x] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[x], sc2, -lq[u])) * (dpt[x] - dl[u]);
         }
         bfg[u] = pack8(ds[0], ds[1]);                      // B[k = key(8g+j)][col = q = cl]
       }
@@ -242,11 +254,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
       for (int db = 0; db < 4; ++db) {
         const bf16x8 kt = tr_frag(Ks, 32 * ss, db * 16, lane);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dq[u][db] = MFMA(kt, bfg[u], dq[u][db]);   // dQ^T[d = 16db+4g+x][q = cl]
+        for (int u = 0; u < U; ++u) dq[u][db] = MFMA(kt, bfg[u], dq[u][db]);   // dQ^T[d = 16db+4g+x][q = cl]
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
       if (qrow[u] < N) {   // a lane owns 4 consecutive head dims of its query row: 8-byte stores
         bf16_t* p = dbase + (size_t)qrow[u] * D3 + 4 * g;
 #pragma unroll
@@ -256,7 +268,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
   }
 }
 
-template <int NF>
+template <int NF, int U, int NW>
 __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                   const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N,
                                                   int H, float scale) {
@@ -266,20 +278,21 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
   float* lse_s = (float*)(Ds + NP * 128);
   float* del_s = lse_s + NP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
+  const float sc2 = scale * 1.4426950408889634f;   // exp(scale s - lse) = 2^(s sc2 - lse log2 e)
   const int b = bh / H, h = bh % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
   const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
   const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
-  stage_tile<NP>(Qs, base, D3, N, tid);
+  stage_tile<NP, 64 * NW>(Qs, base, D3, N, tid);
   // stage dO and form delta = rowsum(dO * O): a row's 8 chunks sit in 8 consecutive lanes
   {
-    constexpr int IT = NP * 8 / 256;
+    constexpr int NT = 64 * NW, IT = (NP * 8 + NT - 1) / NT;
     uint4 dv_[IT], ov_[IT];
     float ls_[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+      int idx = tid + NT * i, row = idx >> 3, c = idx & 7;
       int rc = row < N ? row : N - 1;
       dv_[i] = *(const uint4*)(dobase + (size_t)rc * Dm + c * 8);
       ov_[i] = *(const uint4*)(obase + (size_t)rc * Dm + c * 8);
@@ -287,34 +300,34 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+      int idx = tid + NT * i, row = idx >> 3, c = idx & 7;
       uint4 v = row < N ? dv_[i] : make_uint4(0u, 0u, 0u, 0u);
-      *(uint4*)(Ds + at_off(row, c)) = v;
+      if (NP * 8 % NT == 0 || row < NP) *(uint4*)(Ds + at_off(row, c)) = v;
       float d = dot8(*(bf16x8*)&v, *(bf16x8*)&ov_[i]);
       d += __shfl_xor(d, 1, 64);
       d += __shfl_xor(d, 2, 64);
       d += __shfl_xor(d, 4, 64);
-      if (c == 0) {
+      if (c == 0 && (NP * 8 % NT == 0 || row < NP)) {
         del_s[row] = d;
-        lse_s[row] = row < N ? ls_[i] : 1e30f;   // padded queries: P = exp(. - 1e30) = 0
+        lse_s[row] = row < N ? ls_[i] * 1.4426950408889634f : 1e30f;   // padded queries: P = exp(. - 1e30) = 0
       }
     }
   }
   __syncthreads();
   bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
-  for (int kp = wave; kp < NF / 2; kp += 4) {             // key pair: keys 32 kp .. 32 kp + 31
-    if (kp * 32 >= N) break;
-    bf16x8 kfb[2][2], vfb[2][2];
-    int krow[2];
+  for (int kp = wave; kp < NF / U; kp += NW) {           // key group: keys 16 U kp .. 16 U (kp + 1) - 1
+    if (kp * 16 * U >= N) break;
+    bf16x8 kfb[U][2], vfb[U][2];
+    int krow[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      krow[u] = (2 * kp + u) * 16 + cl;
+    for (int u = 0; u < U; ++u) {
+      krow[u] = (U * kp + u) * 16 + cl;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) { kfb[u][ks] = gfrag(base + Dm, D3, krow[u], N, ks, g); vfb[u][ks] = gfrag(base + 2 * Dm, D3, krow[u], N, ks, g); }
     }
-    f32x4 dv[2][4], dk[2][4];
+    f32x4 dv[U][4], dk[U][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int db = 0; db < 4; ++db) { dv[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
@@ -331,9 +344,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
         lv[hh][0] = l4.x; lv[hh][1] = l4.y; lv[hh][2] = l4.z; lv[hh][3] = l4.w;
         dl[hh][0] = d4.x; dl[hh][1] = d4.y; dl[hh][2] = d4.z; dl[hh][3] = d4.w;
       }
-      bf16x8 pa[2], dsa[2];
+      bf16x8 pa[U], dsa[U];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < U; ++u) {
         f32x4 P[2], dS[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -345,7 +358,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
           }
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
-            const float p = __expf(sa[x] * scale - lv[hh][x]);
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[x], sc2, -lv[hh][x]));
             P[hh][x] = p;
             dS[hh][x] = p * (dpa[x] - dl[hh][x]);
           }
@@ -357,14 +370,14 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
       for (int db = 0; db < 4; ++db) {
         const bf16x8 dt = tr_frag(Ds, 32 * qp, db * 16, lane), qt = tr_frag(Qs, 32 * qp, db * 16, lane);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           dv[u][db] = MFMA(dt, pa[u], dv[u][db]);          // dV^T[d = 16db+4g+x][key = cl]
           dk[u][db] = MFMA(qt, dsa[u], dk[u][db]);         // dK^T[d][key]
         }
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
       if (krow[u] < N) {   // a lane owns 4 consecutive head dims of its key row: 8-byte stores
         bf16_t* pk = dbase + (size_t)krow[u] * D3 + Dm + 4 * g;
         bf16_t* pv = dbase + (size_t)krow[u] * D3 + 2 * Dm + 4 * g;
@@ -383,7 +396,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
 // take 14 + 20 us: each is bound by the SUM of its LDS reads (0.5 KB per MFMA: every wave re-reads the tiles it does not own), its MFMAs and
 // its exponent VALU work, with 2 waves per SIMD and one workgroup per CU (114 KB of LDS) there is nothing to overlap them with, and 384
 // workgroups on 256 CUs leave the second round half empty.  The exponent is folded to one fma + v_exp_f32 here (-2.7 us); the same fold made
-// the two-body kernel 3 us SLOWER stand-alone (39.1 vs 36.1 us, fewer instructions, same registers), so that kernel keeps __expf.
+// the 32-row two-body kernel 3 us SLOWER stand-alone (39.1 vs 36.1 us, fewer instructions, same registers) and the 16-row one 1 us faster.
 #ifdef FC_PROBES
 // ONE workgroup of 8 waves per (batch, head) with Q, K, V and dO tiles all resident in LDS (4 x 28 KB at N = 197): every input row is read
 // from HBM once (the two-body form above stages K, V in one workgroup and Q, dO in another and streams the other pair as fragments:
@@ -605,26 +618,29 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, in
 }
 // dQ and dK/dV of one attention backward in ONE launch: blocks [0, BH) run the dQ bodies, blocks [BH, 2BH) the dK/dV ones.
 // The two are independent; as separate launches on one stream the second waited for the first to drain.
-template <int NF>
-__global__ void __launch_bounds__(256, 2) k_attn_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                     const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
+// U = 16-row blocks a wave owns, NW = waves per workgroup: <2, 4> = 32-row register blocking at 2 waves per SIMD (207 VGPRs);
+// <1, 8> = 16-row blocking under 128 VGPRs, 4 waves per SIMD (twice the LDS fragment reads per MFMA, twice the waves to hide the
+// MFMA -> exponent -> MFMA dependency chain behind)
+template <int NF, int U, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 2) k_attn_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                              const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int half = B * H;
-  if ((int)blockIdx.x < half) attn_bwd_dq_body<NF>(smem, blockIdx.x, qkv, o, dout, lse, dqkv, B, N, H, scale);
-  else attn_bwd_dkv_body<NF>(smem, blockIdx.x - half, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  if ((int)blockIdx.x < half) attn_bwd_dq_body<NF, U, NW>(smem, blockIdx.x, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  else attn_bwd_dkv_body<NF, U, NW>(smem, blockIdx.x - half, qkv, o, dout, lse, dqkv, B, N, H, scale);
 }
-template <int NF>
+template <int NF, int U = 2, int NW = 4>
 static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, bf16_t* dqkv, int B, int N, int H, float scale,
                       hipStream_t s) {
   const int lds_q = 2 * 16 * NF * 128, lds_kv = 2 * 16 * NF * 128 + 2 * 16 * NF * 4;
-  auto kb = k_attn_bwd<NF>;
+  auto kb = k_attn_bwd<NF, U, NW>;
   const int lds = lds_kv > lds_q ? lds_kv : lds_q;
   static bool done = false;
   if (!done) {
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
   }
-  hipLaunchKernelGGL(kb, dim3(B * H * 2), dim3(256), lds, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  hipLaunchKernelGGL(kb, dim3(B * H * 2), dim3(64 * NW), lds, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
   FC_LAUNCH_CHECK();
   return 0;
 }
@@ -671,11 +687,19 @@ int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, con
     if (pick_nf(N) == 16) return launch_bwd_fused<16>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
   }
 #endif
+  // 16-row blocks per wave at twice the waves (8 per workgroup for the image sequences: 110 VGPRs, 4 waves per SIMD) instead of 32-row
+  // blocks at 2 waves per SIMD (206 VGPRs): twice the LDS fragment reads per MFMA -- the LDS is 13 % busy -- for twice the waves to
+  // cover the MFMA -> exponent -> MFMA dependency chain with: 36.0 -> 33.0 us at B = 64, N = 197, 32.0 with the exponent folded into one fma +
+  // v_exp_f32 (that fold made the 32-row form 3 us slower), step -0.5 .. -1 % (profiles/r03/attn_bwd_u1.txt).  Requesting both jobs' Q / dO / O
+  // fragments ahead of the staging (128 VGPRs) measured 33.8 us, skipping the all-padding half of the last 32-row pair in the inner loops
+  // (a wave-uniform branch, 1 / 14 of the work) 33.0 us: neither kept.
+  // FC_ATTN_BWD_U1=0 (tools build) restores the 32-row form.
+  static const int u1 = fc_knob("FC_ATTN_BWD_U1", 1);
   switch (pick_nf(N)) {
-    case 2: return launch_bwd<2>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
-    case 4: return launch_bwd<4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
-    case 14: return launch_bwd<14>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
-    case 16: return launch_bwd<16>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+    case 2: return u1 ? launch_bwd<2, 1, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s) : launch_bwd<2>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+    case 4: return u1 ? launch_bwd<4, 1, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s) : launch_bwd<4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+    case 14: return u1 ? launch_bwd<14, 1, 8>(qkv, o, dout, lse, dqkv, B, N, H, scale, s) : launch_bwd<14>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+    case 16: return u1 ? launch_bwd<16, 1, 8>(qkv, o, dout, lse, dqkv, B, N, H, scale, s) : launch_bwd<16>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
   }
   return 1;
 }

@@ -121,12 +121,14 @@ def test_errors_are_loud():
         cpu_model([torch.zeros(2, 3, 224, 224), None])                   # no CPU fallback
 
 
+@pytest.mark.parametrize("B", [17, 25, 37])
 @pytest.mark.parametrize("kind", ["img+txt", "img"])
-def test_microbatch_chains_do_not_change_the_result(tmp_path, kind):
-    """The image tower runs as two micro-batch chains by default (FC_MICROBATCH, read once per process), with or without a text tower
-    beside it: an odd batch (B = 17 -> 8 + 9) gives the same gradients as the single-chain run up to the order of the LayerNorm
-    partial sums.  'img' = an image classifier with trained re-param linears (its head's weight gradients are taken for the full
-    batch before the chains fork)."""
+def test_microbatch_chains_do_not_change_the_result(tmp_path, kind, B):
+    """The image tower runs as micro-batch chains by default (FC_MICROBATCH, read once per process), with or without a text tower
+    beside it: an odd batch (B = 17 -> 10 + 7 in both directions; B = 25 / 37 -> three forward chains cut at B/3, 2B/3 and two
+    backward chains cut at 57 %) gives the same gradients as the single-chain run up to the order of the LayerNorm partial sums.
+    'img' = an image classifier with trained re-param linears (its head's weight gradients are taken for the full batch before the
+    chains fork)."""
     import os
     import subprocess
     import sys
@@ -137,7 +139,7 @@ def test_microbatch_chains_do_not_change_the_result(tmp_path, kind):
     for mb in ("1", "2"):
         f = str(tmp_path / f"mb{mb}.pt")
         env = dict(os.environ, FC_MICROBATCH=mb, FC_PROBES_LIB="1")
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mb_check.py"), "17", f, kind], env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mb_check.py"), str(B), f, kind], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         out[mb] = torch.load(f)
     for k in out["1"]:
