@@ -234,7 +234,7 @@ class InMemoryPairs:
 def extra_legs(a, args, model, step, B, seq, dev, dev_step_s):
     """h2d_inclusive: the same step with every batch coming from pinned host memory through DevicePrefetcher ("include H2D of
     the batch (pinned, overlapped)").  client_round: FedavgClient.download() + update() (E = 1, 20 steps of B from an in-memory dataset
-    through the client's default loader) + the server's aggregation of that client, in pairs/s.  sustained: >= 2 s of back-to-back steps."""
+    through the client's default loader) + the server's aggregation of that client, in pairs/s.  sustained: >= 6 s of back-to-back steps (long enough for a 5-s utilisation sampler to land inside it)."""
     import copy
     import torch
     from fedcola_amd.loaders import DevicePrefetcher
@@ -260,7 +260,7 @@ def extra_legs(a, args, model, step, B, seq, dev, dev_step_s):
     # ---- sustained
     t0 = time.perf_counter()
     ks = 0
-    while time.perf_counter() - t0 < 2.0:
+    while time.perf_counter() - t0 < 6.0:
         for _ in range(50):
             step()
         ks += 50
