@@ -92,6 +92,12 @@ class FedavgClient(BaseClient):
         if not fused:
             return self._update_unfused(mm, oargs, prox)
         dev = model.flat.device
+        # the first epoch's loader is started NOW: its first batch is assembled (and any sampler RNG is drawn -- nothing below draws from
+        # the CPU generator) while the optimizer state is allocated; fedavgclient.py:79 creates the iterator at the loop head
+        started = None
+        if dev.type == "cuda" and getattr(self.args, "prefetch", True) and self.args.E > 0:
+            from ..loaders.prefetch import DevicePrefetcher       # H2D of the next batches on a copy stream (N4)
+            started = DevicePrefetcher(self.train_loader, dev, depth=2, stream=model.side_stream()).start()
         n = model.flat.numel()
         grads = torch.zeros(n, device=dev)
         exp_avg = torch.zeros(n, device=dev)        # optimizer re-created every round: fresh state (fedavgclient.py:63)
@@ -113,8 +119,10 @@ class FedavgClient(BaseClient):
             lossbuf.zero_()
             broke = False
             loader = self.train_loader
-            if dev.type == "cuda" and getattr(self.args, "prefetch", True):
-                from ..loaders.prefetch import DevicePrefetcher       # H2D of the next batches on a copy stream (N4)
+            if started is not None:
+                loader, started = started, None
+            elif dev.type == "cuda" and getattr(self.args, "prefetch", True):
+                from ..loaders.prefetch import DevicePrefetcher
                 loader = DevicePrefetcher(self.train_loader, dev, depth=2, stream=model.side_stream())
             for batch in loader:
                 if num >= 2 and self.args.debug:                       # fedavgclient.py:73-75
@@ -246,9 +254,38 @@ class FedavgClient(BaseClient):
         mm.aggregate(len(self.test_set))
         return mm.results
 
+    # ---- client models are recycled.  The reference builds a new deep copy of the global model at every download() and the server drops
+    # it after the round (``client.model = None``, fedavgserver.py:501,673).  Here a dropped device model is parked in a small per-process
+    # pool and download() refreshes a parked (or the current) model of the same configuration in place: same values as the deep copy,
+    # without a new library handle, compute-weight buffer and workspace per client and round (0.8 ms + a slow first step of a 100-ms round).
+    _POOL = []
+    _POOL_MAX = 16
+
+    @property
+    def model(self):
+        return self._BaseClient__model
+
+    @model.setter
+    def model(self, model):
+        old = self.__dict__.get("_BaseClient__model")
+        if model is None and old is not None and hasattr(old, "refresh_from") and getattr(old, "flat", None) is not None and old.flat.is_cuda:
+            if len(FedavgClient._POOL) < FedavgClient._POOL_MAX and not any(m is old for m in FedavgClient._POOL):
+                FedavgClient._POOL.append(old)
+        self._BaseClient__model = model
+
     def download(self, models):
-        """fedavgclient.py:155-156 (a device-to-device clone of the flat buffer)."""
-        self.model = copy.deepcopy(models[self.dataset])
+        """fedavgclient.py:155-156 (a device-to-device clone of the flat buffer; into a recycled model object when one fits)."""
+        src = models[self.dataset]
+        if getattr(self.args, "recycle_models", True) and hasattr(src, "refresh_from"):
+            cur = self.__dict__.get("_BaseClient__model")
+            if cur is not None and cur.refresh_from(src):
+                return
+            for i, m in enumerate(FedavgClient._POOL):
+                if m.refresh_from(src):
+                    del FedavgClient._POOL[i]
+                    self._BaseClient__model = m
+                    return
+        self._BaseClient__model = copy.deepcopy(src)
 
     def upload(self):
         """fedavgclient.py:158-184.  Returns the state_dict (device tensors); with ``with_aux`` on a uni-modal client every

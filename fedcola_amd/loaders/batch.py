@@ -76,74 +76,105 @@ class PinnedBatchLoader:
                 bufs[f][j].copy_(torch.as_tensor(v))
 
     def __iter__(self):
+        return _BatchIter(self)
+
+
+class _BatchIter:
+    """One epoch of a PinnedBatchLoader.  An object, not a generator: the RNG draws and the producer thread start when iter() is CALLED,
+    so a caller may create the iterator early and let the first batch be assembled under its own set-up work (FedavgClient.update()
+    starts it before it allocates the optimizer state: 1 ms of a 100-ms round)."""
+
+    def __init__(self, ld: PinnedBatchLoader):
+        self.ld = ld
         # DataLoader.__iter__ draws its base seed from the default RNG before the sampler draws the permutation seed: consume the
         # same number so that a shuffled epoch visits the samples in exactly the DataLoader's order under the same RNG state
         torch.empty((), dtype=torch.int64).random_()
-        sampler = RandomSampler(self.dataset) if self.shuffle else SequentialSampler(self.dataset)
-        batches = list(BatchSampler(sampler, self.batch_size, self.drop_last))      # every RNG draw happens here, in the caller's thread
-        W = self.workers
+        sampler = RandomSampler(ld.dataset) if ld.shuffle else SequentialSampler(ld.dataset)
+        self.batches = list(BatchSampler(sampler, ld.batch_size, ld.drop_last))      # every RNG draw happens here, in the caller's thread
+        self.pool = ld._get_pool()
+        self.pos = 0
+        self.q = None
+        self.stop = threading.Event()
+        self.thread = None
+        if ld.ahead > 0:
+            # a producer thread assembles `ahead` batches in advance, under the consumer's device work
+            self.q = queue.Queue(maxsize=ld.ahead)
+            self.thread = threading.Thread(target=self._produce, daemon=True)
+            self.thread.start()
 
-        def assemble(pool, idxs):
-            n = len(idxs)
-            k = (n + W - 1) // W
-            chunks = [(c * k, idxs[c * k: (c + 1) * k]) for c in range(W) if c * k < n]
-            if hasattr(self.dataset, "get_batch"):          # vectorised fetch (in-memory / pre-decoded datasets): one gather per field and chunk
-                if self._spec is None:                       # field shapes / dtypes: asked once per loader, not once per batch
-                    self._spec = [(tuple(t.shape[1:]), t.dtype) for t in map(torch.as_tensor, self.dataset.get_batch(idxs[:1]))]
-                bufs = [torch.empty((n,) + sh, dtype=dt, pin_memory=self.pin) for sh, dt in self._spec]
+    def _assemble(self, idxs):
+        ld, pool, W = self.ld, self.pool, self.ld.workers
+        n = len(idxs)
+        k = (n + W - 1) // W
+        chunks = [(c * k, idxs[c * k: (c + 1) * k]) for c in range(W) if c * k < n]
+        if hasattr(ld.dataset, "get_batch"):          # vectorised fetch (in-memory / pre-decoded datasets): one gather per field and chunk
+            if ld._spec is None:                       # field shapes / dtypes: asked once per loader, not once per batch
+                ld._spec = [(tuple(t.shape[1:]), t.dtype) for t in map(torch.as_tensor, ld.dataset.get_batch(idxs[:1]))]
+            bufs = [torch.empty((n,) + sh, dtype=dt, pin_memory=ld.pin) for sh, dt in ld._spec]
 
-                def job(ch):
-                    j0, ii = ch
-                    views = [buf[j0: j0 + len(ii)] for buf in bufs]
-                    if self._into:                           # get_batch(indices, out=views): gathered straight into the pinned batch (one copy)
-                        self.dataset.get_batch(ii, out=views)
-                    else:
-                        for v, t in zip(views, self.dataset.get_batch(ii)):
-                            v.copy_(torch.as_tensor(t))
-                list(pool.map(job, chunks))
-                return tuple(bufs)
-            first = [torch.as_tensor(v) for v in self.dataset[idxs[0]]]
-            bufs = [torch.empty((n,) + tuple(t.shape), dtype=t.dtype, pin_memory=self.pin) for t in first]
-            for f, v in enumerate(first):                    # the sample fetched for the shapes is used, not fetched again (one decode, one
-                bufs[f][0].copy_(v)                          # set of RNG draws per sample, like the DataLoader)
-            chunks = [(j0, ii) if j0 else (1, ii[1:]) for j0, ii in chunks]
-            list(pool.map(lambda ch: self._fill_chunk(bufs, ch[0], ch[1]), chunks))
+            def job(ch):
+                j0, ii = ch
+                views = [buf[j0: j0 + len(ii)] for buf in bufs]
+                if ld._into:                           # get_batch(indices, out=views): gathered straight into the pinned batch (one copy)
+                    ld.dataset.get_batch(ii, out=views)
+                else:
+                    for v, t in zip(views, ld.dataset.get_batch(ii)):
+                        v.copy_(torch.as_tensor(t))
+            list(pool.map(job, chunks))
             return tuple(bufs)
+        first = [torch.as_tensor(v) for v in ld.dataset[idxs[0]]]
+        bufs = [torch.empty((n,) + tuple(t.shape), dtype=t.dtype, pin_memory=ld.pin) for t in first]
+        for f, v in enumerate(first):                    # the sample fetched for the shapes is used, not fetched again (one decode, one
+            bufs[f][0].copy_(v)                          # set of RNG draws per sample, like the DataLoader)
+        chunks = [(j0, ii) if j0 else (1, ii[1:]) for j0, ii in chunks]
+        list(pool.map(lambda ch: ld._fill_chunk(bufs, ch[0], ch[1]), chunks))
+        return tuple(bufs)
 
-        pool = self._get_pool()
-        if self.ahead == 0:
-            for idxs in batches:
-                yield assemble(pool, idxs)
-            return
-        # a producer thread assembles `ahead` batches in advance, under the consumer's device work
-        q: "queue.Queue" = queue.Queue(maxsize=self.ahead)
-        stop = threading.Event()
-
-        def produce():
-            try:
-                for idxs in batches:
-                    if stop.is_set():
-                        return
-                    q.put(assemble(pool, idxs))
-                q.put(None)
-            except BaseException as e:      # surfaces in the consumer
-                q.put(e)
-
-        t = threading.Thread(target=produce, daemon=True)
-        t.start()
+    def _produce(self):
         try:
-            while True:
-                item = q.get()
-                if item is None:
+            for idxs in self.batches:
+                if self.stop.is_set():
                     return
-                if isinstance(item, BaseException):
-                    raise item
-                yield item
-        finally:
-            stop.set()
-            while t.is_alive():             # unblock a producer waiting on a full queue
-                try:
-                    q.get_nowait()
-                except queue.Empty:
-                    pass
-                t.join(timeout=0.05)
+                item = self._assemble(idxs)
+                while not self.stop.is_set():
+                    try:
+                        self.q.put(item, timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
+            self.q.put(None)
+        except BaseException as e:      # surfaces in the consumer
+            self.q.put(e)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.q is None:
+            if self.pos >= len(self.batches):
+                raise StopIteration
+            self.pos += 1
+            return self._assemble(self.batches[self.pos - 1])
+        item = self.q.get()
+        if item is None:
+            self.q.put(None)            # stays exhausted
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def close(self):
+        self.stop.set()
+        t, self.thread = self.thread, None
+        while t is not None and t.is_alive():   # unblock a producer waiting on a full queue
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                pass
+            t.join(timeout=0.05)
+
+    def __del__(self):
+        try:
+            self.stop.set()
+        except Exception:
+            pass

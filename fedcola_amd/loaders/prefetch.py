@@ -21,6 +21,14 @@ class DevicePrefetcher:
         self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
         self.stream = stream                   # torch.cuda.Stream / ExternalStream for the copies (default: a new side stream)
         self._pinned = {}                      # (slot, position) -> reusable pinned staging tensor
+        self._it = None
+
+    def start(self):
+        """Create the underlying loader's iterator NOW (a PinnedBatchLoader starts assembling its first batches at that point, and any
+        sampler draws its RNG numbers here) and keep it for the coming __iter__: lets the caller overlap its own set-up with the first
+        batch.  Returns self."""
+        self._it = iter(self.loader)
+        return self
 
     def __len__(self):
         return len(self.loader)
@@ -55,7 +63,8 @@ class DevicePrefetcher:
         stream = self.stream if self.stream is not None else torch.cuda.Stream(device=self.device)
         pending = deque()
         nslots = self.depth + 1                # a slot's pinned buffers are reused only after its batch has been consumed
-        it = iter(self.loader)
+        it, self._it = (self._it if self._it is not None else iter(self.loader)), None
+        src = it
         slot = 0
         done_events = {}                       # slot -> event after which its pinned buffers may be overwritten
         first = True
@@ -85,3 +94,5 @@ class DevicePrefetcher:
                 yield tensors
         finally:
             pending.clear()
+            if hasattr(src, "close"):          # an abandoned epoch (debug break): stop the loader's producer thread
+                src.close()

@@ -337,6 +337,36 @@ class ModalityAgnosticTransformer(nn.Module):
         new.train(self.training)
         return new
 
+    def refresh_from(self, src) -> bool:
+        """Make this model an exact copy of ``src`` WITHOUT building a new object: what ``copy.deepcopy(src)`` returns, when this model
+        already has src's configuration (same library configuration struct, precision, device, segment list).  The library handle, the
+        bf16 compute-weight buffer and the workspace stay allocated -- a FedavgClient's download() at every round (fedavgclient.py:155)
+        otherwise pays a new handle, its device tables and a 3.6-GB workspace claim before its first step.  Returns False (nothing
+        touched) when the two models are not interchangeable; the caller then deep-copies."""
+        if type(src) is not type(self) or src is self:
+            return False
+        if self.flat.device != src.flat.device or self.flat.shape != src.flat.shape or self.flat.dtype != src.flat.dtype:
+            return False
+        if bytes(self._handle.cfg) != bytes(src._handle.cfg) or self.precision != src.precision:
+            return False
+        if list(self.segments.keys()) != list(src.segments.keys()):
+            return False
+        for k, s in src.segments.items():                                # freeze flags follow the source (as in __deepcopy__)
+            if self.segments[k]["trainable"] != s["trainable"]:
+                self.set_trainable(k, s["trainable"])
+        skip = ("_parameters", "_buffers", "_modules", "_wc", "_ws", "_views", "_handle", "_dp_keep", "_agg_partial", "segments", "training",
+                "_wc_version")
+        for k, v in src.__dict__.items():                                # plain Python state (hyper-parameters, alias maps, rates)
+            if k not in skip:
+                self.__dict__[k] = copy.deepcopy(v)
+        with torch.no_grad():
+            self.flat.data.copy_(src.flat.data)
+        self.flat.grad = None
+        self._views = None
+        self._bump()                                                     # the compute weights are re-cast before the next forward
+        self.train(src.training)
+        return True
+
     def set_trainable(self, key: str, flag: bool):
         check(_lib.lib().fc_model_set_trainable(self._handle.h, self.segments[key]["index"], int(flag)))
         self.segments[key]["trainable"] = bool(flag)

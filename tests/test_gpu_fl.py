@@ -73,6 +73,59 @@ def test_client_update_matches_reference_result_dict(fused):
         assert err.max() <= 2.5e-3, k
 
 
+def test_recycled_client_model_is_the_deep_copy_the_reference_makes():
+    """download() refreshes a recycled model object in place (FedavgClient._POOL / the client's current model) instead of building a new
+    deep copy (fedavgclient.py:155-156): the recycled model must be indistinguishable from the deep copy -- weights, freeze flags, mode --
+    whatever the previous round left in it, must not alias the global model, and a second round of update() on it must give the result
+    the first round gave on a fresh copy."""
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    rec = G.load("update_toy.json")
+    args = RefArgs(E=rec["E"], B=rec["B"], lr=rec["lr"], optimizer="AdamW", no_shuffle=True, max_grad_norm=0.0)
+    ds = SynthPairs(rec["n"], 8, 30)
+    cl = FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cuda"
+    FedavgClient._POOL.clear()
+    g = toy_model()
+    cl.download({"Flickr30k": g})
+    first = cl.model
+    assert first is not g and first.flat.data_ptr() != g.flat.data_ptr()
+    res1 = cl.update()
+    after1 = {k: v.detach().clone() for k, v in cl.model.state_dict().items()}
+    # leave traces a deep copy would not have: a frozen segment, eval mode, trained weights
+    k0 = next(iter(first.segments))
+    first.set_trainable(k0, False)
+    first.eval()
+    cl.model = None                                                        # what the server does after a round: parks the model
+    assert len(FedavgClient._POOL) == 1 and cl.model is None
+    cl.download({"Flickr30k": g})
+    assert cl.model is first and not FedavgClient._POOL                    # recycled, not rebuilt
+    ref = copy.deepcopy(g)
+    assert cl.model.training == ref.training
+    for k, v in ref.state_dict().items():
+        assert torch.equal(cl.model.state_dict()[k], v), k
+    assert all(cl.model.segments[k]["trainable"] == s["trainable"] for k, s in ref.segments.items())
+    res2 = cl.update()
+    for e in res1:
+        assert abs(res1[e]["loss"] - res2[e]["loss"]) <= 1e-6, (res1[e], res2[e])
+    for k, v in cl.model.state_dict().items():                              # atomically accumulated embedding gradients: run-to-run noise only
+        err = (v - after1[k]).abs()
+        if k.endswith("attn.qkv.bias"):                                     # the key bias: exactly-zero true gradient, Adam steps on round-off
+            D = err.numel() // 3
+            err[D:2 * D] = 0
+        assert float(err.max()) <= 1e-5 * max(1.0, float(after1[k].abs().max())), k
+    assert torch.equal(g.state_dict()[k0], toy_model().state_dict()[k0])    # the global model was never written
+    # a model of another configuration is not taken from the pool
+    cl.model = None
+    other = FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
+    other.id, other.dataset, other.device = 1, "Flickr30k", "cuda"
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    mk = dict(G.load("model_toy.json")["mk"]); mk["depth"] = mk.get("depth", 1) + 1
+    g2 = M(precision="fp32", **mk).cuda()
+    other.download({"Flickr30k": g2})
+    assert other.model is not first and len(FedavgClient._POOL) == 1
+    FedavgClient._POOL.clear()
+
+
 @pytest.mark.parametrize("idx", range(7))
 def test_device_aggregation_vs_golden(idx):
     rec = G.load("agg.json")[idx]

@@ -362,3 +362,30 @@ def test_fc_model_cfg_fields_agree_between_header_binding_and_integration_doc():
     seg = re.sub(r"/\*.*?\*/", "", seg, flags=re.S)
     seg_fields = [re.split(r"[\s\[]", d.strip().split()[-1])[0] for d in seg.split(";") if d.strip()]
     assert [n for n, t in _lib.FcSegment._fields_] == seg_fields
+
+
+def test_refresh_from_equals_deepcopy_on_the_host():
+    """ModalityAgnosticTransformer.refresh_from (what FedavgClient.download() uses to recycle a model object): same weights, freeze flags,
+    mode and Python state as copy.deepcopy(src); refuses a model of another configuration without touching it."""
+    import copy
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    mk = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=4, depth=2, num_heads=2, vocab_size=30,
+              max_text_len=8)
+    torch.manual_seed(1)
+    src, dst = M(**mk), M(**mk)
+    with torch.no_grad():
+        dst.flat.mul_(3.0).add_(1.0)
+    k0 = list(src.segments)[3]
+    src.set_trainable(k0, False)
+    dst.eval()
+    assert dst.refresh_from(src) is True
+    ref = copy.deepcopy(src)
+    assert dst.training == ref.training and dst.flat.data_ptr() != src.flat.data_ptr()
+    for k, v in ref.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    assert [s["trainable"] for s in dst.segments.values()] == [s["trainable"] for s in ref.segments.values()]
+    assert [n for n, p in dst.named_parameters()] == [n for n, p in ref.named_parameters()]
+    other = M(**dict(mk, depth=3))
+    before = other.flat.detach().clone()
+    assert other.refresh_from(src) is False and torch.equal(other.flat, before)
+    assert src.refresh_from(src) is False
