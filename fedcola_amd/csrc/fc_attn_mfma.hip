@@ -74,7 +74,9 @@ __device__ __forceinline__ void stage_tile(char* T, const bf16_t* __restrict__ s
 // wave and paid a dependent Q load in each: 18.8 us at B = 64 for 3.8 GFLOP).
 #define AF_WAVES 8
 #define AF_QB 2        // query blocks per wave held in registers (N <= 16 * AF_WAVES * AF_QB = 256)
-template <int NF>  // key fragments of 16 (Npad = 16*NF, NF even)
+// NV = key blocks that hold real keys (compile time, so that the block loop stays straight-line code: a run-time test per block
+// serialises it into read -> wait -> MFMA -> wait chains); MASKALL = false promises N > 16 (NV - 1): only block NV - 1 straddles N.
+template <int NF, int NV = NF, bool MASKALL = true>  // key fragments of 16 (Npad = 16*NF, NF even)
 __global__ void __launch_bounds__(64 * AF_WAVES) k_attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse, int B, int N,
                                                                  int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,16 +109,15 @@ __global__ void __launch_bounds__(64 * AF_WAVES) k_attn_fwd_mfma(const bf16_t* _
     const int qrow = qb * 16 + cl;
     f32x4 s[NF];
     float m = -INFINITY;
-    // key blocks past N (block 13 of 14 at N = 197) are skipped, and only the block that straddles N pays the mask: both tests are
-    // wave-uniform (scalar branches)
+    // key blocks past N (block 13 of 14 at N = 197) are skipped, and only the block that straddles N pays the mask
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       f32x4 a = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (f * 16 < N) {
+      if (f < NV) {
         a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) a = MFMA(row_frag(Ks, f * 16, ks, lane), qf[r][ks], a);   // S^T[key = 16f+4g+x][q = cl]
-        if (f * 16 + 16 > N) {
+        if (MASKALL || f == NV - 1) {
 #pragma unroll
           for (int x = 0; x < 4; ++x) a[x] = (f * 16 + 4 * g + x < N) ? a[x] : -INFINITY;   // raw scores: the scale rides in the exponent's fma below
         }
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(64 * AF_WAVES) k_attn_fwd_mfma(const bf16_t* _
     const float sc2 = scale * 1.4426950408889634f, m2 = m * sc2;                    // exp(scale (s - m)) = 2^(s sc2 - m sc2): one fma + v_exp_f32 per score
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      if (f * 16 < N) {
+      if (f < NV) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) { float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][x], sc2, -m2)); s[f][x] = p; sum += p; }
       } else {
@@ -144,8 +145,7 @@ __global__ void __launch_bounds__(64 * AF_WAVES) k_attn_fwd_mfma(const bf16_t* _
 #pragma unroll
     for (int db = 0; db < 4; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ss = 0; ss < NF / 2; ++ss) {
-      if (ss * 32 >= N) break;
+    for (int ss = 0; ss < (NV + 1) / 2; ++ss) {
       bf16x8 pb = pack8(s[2 * ss], s[2 * ss + 1]);                      // P^T[key(8g+j)][q = cl]
 #pragma unroll
       for (int db = 0; db < 4; ++db) oacc[db] = MFMA(tr_frag(Vs, 32 * ss, db * 16, lane), pb, oacc[db]);   // O^T[d = 16db+4g+x][q]
@@ -606,10 +606,10 @@ __global__ void __launch_bounds__(64 * AB_WAVES, 2) k_attn_bwd_fused(const bf16_
 // ======================================================================== launchers
 static int pick_nf(int N) { return N <= 32 ? 2 : N <= 64 ? 4 : N <= 224 ? 14 : N <= 256 ? 16 : 0; }
 
-template <int NF>
+template <int NF, int NV = NF, bool MASKALL = true>
 static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
   const int lds = 2 * 16 * NF * 128;
-  auto k = k_attn_fwd_mfma<NF>;
+  auto k = k_attn_fwd_mfma<NF, NV, MASKALL>;
   static bool done = false;
   if (!done) { FC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); done = true; }
   hipLaunchKernelGGL(k, dim3(B * H), dim3(64 * AF_WAVES), lds, s, qkv, o, lse, B, N, H, scale);
@@ -651,7 +651,9 @@ int fc_attn_fwd_mfma(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int
   switch (pick_nf(N)) {
     case 2: return launch_fwd<2>(qkv, o, lse, B, N, H, scale, s);
     case 4: return launch_fwd<4>(qkv, o, lse, B, N, H, scale, s);
-    case 14: return launch_fwd<14>(qkv, o, lse, B, N, H, scale, s);
+    case 14:
+      if (N > 192 && N <= 208) return launch_fwd<14, 13, false>(qkv, o, lse, B, N, H, scale, s);   // ViT /16 at 224: 197 tokens = 12 full blocks + 5 keys
+      return launch_fwd<14>(qkv, o, lse, B, N, H, scale, s);
     case 16: return launch_fwd<16>(qkv, o, lse, B, N, H, scale, s);
   }
   return 1;
