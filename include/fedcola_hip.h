@@ -10,10 +10,11 @@
  * device/stream.
  * Allocation / synchronisation: the steady state (same handle, same workspace address, same batch shape) allocates nothing
  * and never blocks the host.  The exceptions, each once: the first forward of a process creates the library's internal HIP
- * streams for the device and measures which of them run concurrently (~10 ms); the first backward of a handle allocates its
- * table buffers (weight-gradient problems, LayerNorm reductions; the first fc_client_step also the optimizer's chunk table, a
- * colearn_attn model the shared-gradient chunk table: < 64 KB each, one device synchronisation, freed by fc_model_destroy); a call
- * whose workspace address or batch shape differs from the previous one re-sends those tables (one stream synchronisation);
+ * streams for the device and measures which of them run concurrently (~10 ms); the first backward over a given set of buffers and
+ * batch shape uploads its device tables (weight-gradient problems, LayerNorm reductions; fc_client_step also the optimizer's chunk
+ * table, a colearn_attn model the shared-gradient chunk table: < 64 KB each, one allocation + one synchronous copy).  The tables are
+ * cached per process by CONTENT: another handle of the same configuration over the same addresses, or a return to an earlier
+ * workspace / batch shape, finds them and uploads nothing (the cache is dropped, with one device synchronisation, after 1024 entries);
  * fc_prox_term / fc_clip_grad_norm copy a <= 50-KB table from host memory on every call (their scratch is the caller's and may
  * have been reused in between); fc_comm_create builds an RCCL communicator; the fc_k_* test entry points synchronise where their
  * comment says so.
