@@ -452,9 +452,19 @@ def main():
         global_model = create_model("mome_small_patch16", False, args=args, num_classes=[None, None], modalities=["img", "txt"],
                                     tasks=["rtv", "rtv"]).to(dev)
         comm_c = None
+        cabi_error = None
         if not (one_device and os.environ.get("FC_BENCH_BACKEND", "gloo") == "gloo"):     # RCCL refuses two ranks on one device
             from fedcola_amd.comm import Comm
-            comm_c = Comm.from_torch_dist()
+            try:
+                comm_c = Comm.from_torch_dist()
+            except Exception as e:                                         # keep the run: the torch.distributed path is RCCL as well
+                cabi_error = f"{type(e).__name__}: {e}"[:300]
+            ok = torch.tensor([0 if comm_c is None else 1], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                      # every rank takes the same path
+            if int(ok) == 0 and comm_c is not None:
+                comm_c.close()
+                comm_c = None
+                cabi_error = "another rank could not create the C-ABI communicator"
         comm = comm_c if a.agg == "cabi" else None
 
     agg_state = {}
@@ -606,6 +616,8 @@ def main():
             out["aggregate_GBps"] = round(4 * n / agg_s / 1e9, 2)
             out["allreduce_bus_GBps"] = round(2 * (world - 1) / world * 4 * n / agg_s / 1e9, 2)
             out.update(selfcheck)
+            if cabi_error:
+                out["cabi_comm_error"] = cabi_error
         out.update(extra)
         if drop_line is not None:
             out["dropout_0p1"] = drop_line
