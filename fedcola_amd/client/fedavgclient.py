@@ -259,7 +259,7 @@ class FedavgClient(BaseClient):
     # pool and download() refreshes a parked (or the current) model of the same configuration in place: same values as the deep copy,
     # without a new library handle, compute-weight buffer and workspace per client and round (0.8 ms + a slow first step of a 100-ms round).
     _POOL = []
-    _POOL_MAX = 16
+    _POOL_MAX = 8
 
     @property
     def model(self):
