@@ -144,7 +144,10 @@ def attn_ref(qkv, B, N, H, d):
 
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("B,N,H,d", [(2, 5, 2, 2), (3, 197, 3, 64), (2, 32, 6, 64), (2, 16, 1, 64), (1, 40, 2, 32), (2, 70, 2, 64)])
+# 193 / 208: first and last sequence length of the 13-valid-key-block forward specialisation (12 full blocks + 1 .. 16 keys), 209 / 224:
+# the generic 14-block form beside it, 256: the 16-block form at its limit, 145: a 192-pixel image
+@pytest.mark.parametrize("B,N,H,d", [(2, 5, 2, 2), (3, 197, 3, 64), (2, 32, 6, 64), (2, 16, 1, 64), (1, 40, 2, 32), (2, 70, 2, 64),
+                                     (2, 193, 2, 64), (1, 208, 2, 64), (1, 209, 2, 64), (1, 224, 1, 64), (1, 256, 1, 64), (2, 145, 2, 64)])
 def test_attention(impl, prec, B, N, H, d):
     if impl == 1 and prec == "fp32":
         pytest.skip("MFMA path is bf16")
