@@ -258,6 +258,31 @@ def test_vit_tiny_img_client_bf16_layer_by_layer():
     print("ViT-Tiny layer-by-layer worst:", worst)
 
 
+def test_other_image_size_and_odd_batch_bf16_layer_by_layer():
+    """Shapes beside the benchmark's: a 160-pixel image (101 tokens: the generic 14-block attention forms with masked keys, GEMM row
+    tiles that end mid-tile), a 24-token caption, B = 27 (three forward chains of 9, backward chains of 15 + 12), ViT-S width, 3 layers --
+    teacher-forced per layer against the emulating oracle, both towers."""
+    mk = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=384, depth=3, num_heads=6, vocab_size=500,
+              max_text_len=24, img_size=160)
+    sd = _default_init(mk, 29)
+    B, D, H, seq = 27, 384, 6, 24
+    g = torch.Generator().manual_seed(123)
+    img = (torch.randn(B, 3, 160, 160, generator=g) * 0.5).clamp_(-1, 1)
+    ids = torch.randint(1, 500, (B, seq), generator=g)
+    lens = torch.randint(5, seq + 1, (B,), generator=g)
+    ids[torch.arange(seq)[None, :] >= lens[:, None]] = 0
+    model = PU.build_product(mk, "bf16", sd)
+    model.train()
+    loss, grads, _ = PU.product_step(model, "img+txt", img, ids, None, 1e-4)
+    worst = ("", 0.0)
+    for tower, N in ((0, 101), (1, seq)):
+        for l in range(3):
+            w = _layer_local(model, sd, grads, B, seq, tower, N, l, D, H)
+            if w[1] > worst[1]:
+                worst = w
+    print("160-pixel / B = 27 layer-by-layer worst:", worst)
+
+
 def test_vit_b_full_depth_bf16_layer_by_layer():
     """BASELINE.json config[3]'s model at its stated size -- ViT-B/16 + BERT-base width (768 wide, 12 layers, 12 heads, vocab 30 522,
     40-token captions), img+txt client, B = 32 -- teacher-forced per layer against the emulating oracle (first and last layer of
