@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256) k_txt_embed_bwd_v(const T* __restrict__ d
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ g, float* dword, float* dpos, float* dtype, float* dg,
                                                          float* db, int B, int N, int D, int vocab) {
-  extern __shared__ float red_dyn[];   // [4 waves][3][D]
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];   // [4 waves][3][D] | [4 waves][4 rows][144]: transposition scratch of the word-gradient atomics
   const int n = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 15, slot = lane >> 4;
   const int nc = D >> 3;
   const int bi = blockIdx.y * 16 + wave * 4 + slot;
@@ -382,9 +382,25 @@ __global__ void __launch_bounds__(256) k_txt_embed_bwd_v(const T* __restrict__ d
       gm[i] = live ? d[t][i] * xh[t][i] : 0.f;
       bt[i] = live ? d[t][i] : 0.f;
     }
-    if (c < nc && live && id != 0) {
+    // word-table gradient: a lane holds 8 CONSECUTIVE columns of its row, which as atomics would touch four 128-B lines per instruction and
+    // row (16 lanes x 32-B stride).  The 16 lanes of a row swap through LDS so that instruction j adds columns {lane + 16 j}: one 64-B run
+    // per row and instruction, a quarter of the line requests at the L2 atomic units (12 of the kernel's 26 us were these atomics).
+    {
+      float* tr = red_dyn + 12 * D + (wave * 4 + slot) * 144;          // 128 columns of this row's chunk, rows 144 floats apart (banks)
+      *(float4*)(tr + 8 * sub) = make_float4(de[0], de[1], de[2], de[3]);
+      *(float4*)(tr + 8 * sub + 4) = make_float4(de[4], de[5], de[6], de[7]);
+      // same wave, same row group: the LDS write above is visible to the reads below once lgkmcnt drains (no barrier needed)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (live && id != 0) {
+        float* wrow = dword + (size_t)id * D + 128 * t;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) atomicAdd(dword + (size_t)id * D + c * 8 + i, de[i]);
+        for (int j = 0; j < 8; ++j) {
+          const int col = sub + 16 * j;
+          if (128 * t + col < D) atomicAdd(wrow + col, tr[col]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {    // the wave's four rows
@@ -415,7 +431,7 @@ int fc_txt_embed_bwd(int dt, const void* dy, const int64_t* ids, const float* wo
                      int vocab, hipStream_t s) {
   if ((D & 7) == 0 && D <= 1024 && !(((uintptr_t)dy | (uintptr_t)word | (uintptr_t)pos | (uintptr_t)type | (uintptr_t)g) & 15)) {
     const int ch = fc_cdiv(D / 8, 16);
-    const size_t lds = sizeof(float) * 12 * D;
+    const size_t lds = sizeof(float) * (12 * D + 16 * 144);
 #define GO(CHN) DISPATCH_DT(dt, hipLaunchKernelGGL((k_txt_embed_bwd_v<T, CHN>), dim3(N, fc_cdiv(B, 16)), dim3(256), lds, s, (const T*)dy, ids, word, pos, type, \
                                                    mean, rstd, g, dword, dpos, dtype, dg, db, B, N, D, vocab))
     switch (ch) {
