@@ -233,7 +233,60 @@ __global__ void __launch_bounds__(256) k_img_embed_bwd(const T* __restrict__ dx,
     if (n == 0) atomicAdd(dcls + i, s);
   }
 }
+// 16-byte vector form (D % 8 == 0, D <= 1024): block = (token position n, 16 images), 16 lanes per row with 8 columns each (as in
+// fc_ln.hip), so that the rows spread over N x B/16 blocks and every access is a whole 16-B chunk; the block's column sums go through
+// registers and LDS to one atomic per column per block.  (The one-block-per-position form above walks the batch serially with 2-byte
+// loads: 29 us at the end of each backward image chain, in front of the last weight-gradient chunk.)
+template <typename T, int CH>
+__global__ void __launch_bounds__(256) k_img_embed_bwd_v(const T* __restrict__ dx, float* __restrict__ dpos, float* __restrict__ dcls,
+                                                         T* __restrict__ dtok, int B, int N, int D) {
+  extern __shared__ __attribute__((aligned(16))) float red_img[];   // [4 waves][D]
+  const int n = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 15, slot = lane >> 4;
+  const int nc = D >> 3;
+  const int bi = blockIdx.y * 16 + wave * 4 + slot;
+  const bool live = bi < B;
+  const T* src = dx + ((size_t)(live ? bi : 0) * N + n) * D;
+  float acc[CH][8];
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = sub + 16 * t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+    if (c < nc && live) {
+      V8<T>::ld(src + c * 8, acc[t]);
+      if (n > 0) V8<T>::st(dtok + ((size_t)bi * (N - 1) + (n - 1)) * D + c * 8, acc[t]);   // same values back: a row copy
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = sub + 16 * t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc[t][i] += __shfl_xor(acc[t][i], 16, 64); acc[t][i] += __shfl_xor(acc[t][i], 32, 64); }   // the wave's four rows
+    if (slot == 0 && c < nc) {
+      *(float4*)(red_img + wave * D + c * 8) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+      *(float4*)(red_img + wave * D + c * 8 + 4) = make_float4(acc[t][4], acc[t][5], acc[t][6], acc[t][7]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float v = red_img[i] + red_img[D + i] + red_img[2 * D + i] + red_img[3 * D + i];
+    atomicAdd(dpos + (size_t)n * D + i, v);
+    if (n == 0) atomicAdd(dcls + i, v);
+  }
+}
 int fc_img_embed_bwd(int dt, const void* dx, float* dpos, float* dcls, void* dtok, int B, int N, int D, hipStream_t s) {
+  if ((D & 7) == 0 && D <= 1024 && !(((uintptr_t)dx | (uintptr_t)dtok) & 15)) {
+    const int ch = fc_cdiv(D / 8, 16);
+    const size_t lds = sizeof(float) * 4 * D;
+#define GO(CHN) DISPATCH_DT(dt, hipLaunchKernelGGL((k_img_embed_bwd_v<T, CHN>), dim3(N, fc_cdiv(B, 16)), dim3(256), lds, s, (const T*)dx, dpos, dcls, (T*)dtok, B, N, D))
+    switch (ch) {
+      case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
+      case 5: case 6: GO(6); break; default: GO(8); break;
+    }
+#undef GO
+    FC_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_DT(dt, hipLaunchKernelGGL(k_img_embed_bwd<T>, dim3(N), dim3(256), 0, s, (const T*)dx, dpos, dcls, (T*)dtok, B, N, D));
   FC_LAUNCH_CHECK();
   return 0;
