@@ -198,8 +198,32 @@ __global__ void __launch_bounds__(256) k_patchify(const float* __restrict__ img,
     Io<T>::st(out, idx, img[(((size_t)b * C + c) * HW + (py * P + ph)) * HW + px * P + pw]);
   }
 }
+// 8 pixels of one patch row per thread (P % 8 == 0): two 16-B reads, one 16-B (bf16) store, output order = thread order.  The scalar form
+// above moved 19 MB in 35 us at the head of every forward image chain.
+template <typename T>
+__global__ void __launch_bounds__(256) k_patchify_v(const float* __restrict__ img, T* __restrict__ out, int B, int C, int HW, int P) {
+  const int gw = HW / P, np = gw * gw, K = C * P * P, K8 = K >> 3, PP = P * P;
+  const size_t units = (size_t)B * np * K8;
+  for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
+    const int k = (int)(u % K8) * 8;
+    const size_t r = u / K8;
+    const int p = (int)(r % np), b = (int)(r / np);
+    const int c = k / PP, ph = (k / P) % P, pw = k % P;
+    const int py = p / gw, px = p % gw;
+    float v[8];
+    V8<float>::ld(img + (((size_t)b * C + c) * HW + (py * P + ph)) * HW + px * P + pw, v);
+    V8<T>::st(out + u * 8, v);
+  }
+}
 int fc_patchify(int dt, const float* img, void* patches, int B, int C, int HW, int P, hipStream_t s) {
   size_t total = (size_t)B * (HW / P) * (HW / P) * C * P * P;
+  if ((P & 7) == 0 && (HW & 3) == 0 && !(((uintptr_t)img | (uintptr_t)patches) & 15)) {
+    const size_t units = total / 8;
+    int grid = (int)((units + 255) / 256 > 16384 ? 16384 : (units + 255) / 256);
+    DISPATCH_DT(dt, hipLaunchKernelGGL(k_patchify_v<T>, dim3(grid), dim3(256), 0, s, img, (T*)patches, B, C, HW, P));
+    FC_LAUNCH_CHECK();
+    return 0;
+  }
   int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   DISPATCH_DT(dt, hipLaunchKernelGGL(k_patchify<T>, dim3(grid), dim3(256), 0, s, img, (T*)patches, B, C, HW, P));
   FC_LAUNCH_CHECK();
