@@ -533,6 +533,40 @@ __global__ void __launch_bounds__(64) k_head_fwd(const T* __restrict__ x, const 
                                                  int normalize) {
   int bi = blockIdx.x, lane = threadIdx.x;
   const T* xr = x + (size_t)bi * N * D;
+  if (D <= 1024) {                                      // the row lives in registers: one memory round trip instead of three dependent ones
+    float xv[16], gv[16], bv[16];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + 64 * k;
+      xv[k] = i < D ? Io<T>::ld(xr, i) : 0.f;
+      gv[k] = i < D ? g[i] : 0.f;
+      bv[k] = i < D ? b[i] : 0.f;
+      s += xv[k];
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const float d = lane + 64 * k < D ? xv[k] - mu : 0.f; q += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    float n2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      xv[k] = (xv[k] - mu) * rs * gv[k] + bv[k];
+      if (lane + 64 * k < D) n2 += xv[k] * xv[k];
+    }
+    const float nr = sqrtf(wave_sum(n2));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + 64 * k;
+      if (i < D) {
+        f[(size_t)bi * D + i] = xv[k];
+        if (normalize) out[(size_t)bi * D + i] = xv[k] / nr;
+      }
+    }
+    if (lane == 0) { mean[bi] = mu; rstd[bi] = rs; nrm[bi] = nr; }
+    return;
+  }
   float s = 0.f;
   for (int i = lane; i < D; i += 64) s += Io<T>::ld(xr, i);
   float mu = wave_sum(s) / (float)D;
@@ -565,8 +599,13 @@ __global__ void __launch_bounds__(256) k_head_bwd(const float* __restrict__ din,
   int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= B * N) return;
   T* dxr = dx + (size_t)row * D;
-  if (row % N != 0) {
-    for (int i = lane; i < D; i += 64) Io<T>::st(dxr, i, 0.f);
+  if (row % N != 0) {                                   // no gradient reaches the non-cls rows through the head: zero rows, 16 bytes per lane
+    if (((D * sizeof(T)) & 15) == 0 && (((uintptr_t)dx) & 15) == 0) {
+      const int n16 = (int)(D * sizeof(T) / 16);
+      for (int c = lane; c < n16; c += 64) ((uint4*)dxr)[c] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (int i = lane; i < D; i += 64) Io<T>::st(dxr, i, 0.f);
+    }
     return;
   }
   int bi = row / N;
