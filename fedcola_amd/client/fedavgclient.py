@@ -268,7 +268,8 @@ class FedavgClient(BaseClient):
     @model.setter
     def model(self, model):
         old = self.__dict__.get("_BaseClient__model")
-        if model is None and old is not None and hasattr(old, "refresh_from") and getattr(old, "flat", None) is not None and old.flat.is_cuda:
+        # only a model this class built in download() may be recycled: an object somebody assigned (a global model, say) is never written to
+        if model is None and old is not None and getattr(old, "_client_owned", False) and getattr(old, "flat", None) is not None and old.flat.is_cuda:
             if len(FedavgClient._POOL) < FedavgClient._POOL_MAX and not any(m is old for m in FedavgClient._POOL):
                 FedavgClient._POOL.append(old)
         self._BaseClient__model = model
@@ -278,14 +279,18 @@ class FedavgClient(BaseClient):
         src = models[self.dataset]
         if getattr(self.args, "recycle_models", True) and hasattr(src, "refresh_from"):
             cur = self.__dict__.get("_BaseClient__model")
-            if cur is not None and cur.refresh_from(src):
+            if cur is not None and getattr(cur, "_client_owned", False) and cur.refresh_from(src):
                 return
             for i, m in enumerate(FedavgClient._POOL):
                 if m.refresh_from(src):
                     del FedavgClient._POOL[i]
+                    m._client_owned = True
                     self._BaseClient__model = m
                     return
-        self._BaseClient__model = copy.deepcopy(src)
+        m = copy.deepcopy(src)
+        if hasattr(m, "refresh_from"):
+            m._client_owned = True
+        self._BaseClient__model = m
 
     def upload(self):
         """fedavgclient.py:158-184.  Returns the state_dict (device tensors); with ``with_aux`` on a uni-modal client every

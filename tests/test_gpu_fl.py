@@ -114,6 +114,14 @@ def test_recycled_client_model_is_the_deep_copy_the_reference_makes():
             err[D:2 * D] = 0
         assert float(err.max()) <= 1e-5 * max(1.0, float(after1[k].abs().max())), k
     assert torch.equal(g.state_dict()[k0], toy_model().state_dict()[k0])    # the global model was never written
+    # an object somebody ASSIGNED (the global model itself, say) is never parked: download() must not be able to write into it later
+    cl.model = None
+    FedavgClient._POOL.clear()
+    cl.model = g
+    cl.model = None
+    assert not FedavgClient._POOL
+    cl.download({"Flickr30k": g})
+    assert cl.model is not g
     # a model of another configuration is not taken from the pool
     cl.model = None
     other = FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
