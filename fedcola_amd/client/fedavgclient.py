@@ -258,6 +258,8 @@ class FedavgClient(BaseClient):
     # it after the round (``client.model = None``, fedavgserver.py:501,673).  Here a dropped device model is parked in a small per-process
     # pool and download() refreshes a parked (or the current) model of the same configuration in place: same values as the deep copy,
     # without a new library handle, compute-weight buffer and workspace per client and round (0.8 ms + a slow first step of a 100-ms round).
+    # Consequence: tensors handed out by upload() / state_dict() of a client model are views that stay valid until a later download()
+    # recycles that model (the server consumes them within the round); ``args.recycle_models = False`` restores a fresh deep copy per round.
     _POOL = []
     _POOL_MAX = 8
 
