@@ -34,6 +34,8 @@ struct FcLnReduce {
   float* dg;
   float* db;
   int nblocks, nblocks2, D, accumulate;
+  const float* partial3;   // a third micro-batch chain's partial rows (three-chain backward)
+  int nblocks3, pad_;
 };
 int fc_layernorm_bwd_partial_blocks(int M);
 int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s);

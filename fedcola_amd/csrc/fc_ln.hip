@@ -244,6 +244,8 @@ __global__ void __launch_bounds__(1024) k_ln_reduce(const FcLnReduce* __restrict
     for (int bk = wave; bk < e.nblocks; bk += 16) acc += e.partial[(size_t)bk * W + col];
   if (e.partial2 && col < W)
     for (int bk = wave; bk < e.nblocks2; bk += 16) acc += e.partial2[(size_t)bk * W + col];
+  if (e.partial3 && col < W)
+    for (int bk = wave; bk < e.nblocks3; bk += 16) acc += e.partial3[(size_t)bk * W + col];
   red[wave][threadIdx.x & 63] = acc;
   __syncthreads();
   if (wave == 0 && col < W) {

@@ -344,7 +344,7 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
     t.dO = bp.take((size_t)t.M * D * es);
     t.delta = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * t.N);
     t.ln_stride = ((size_t)fc_layernorm_bwd_partial_blocks(t.M) + 1) * 2 * D;                  // (+1: a slice may round up once more)
-    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)2 * 2 * c.depth * t.ln_stride);   // x2: micro-batch chains
+    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)3 * 2 * c.depth * t.ln_stride);   // x3: micro-batch chains
   }
   w.max_probs = 2 * (4 * c.depth + 1);
   w.probs = (FcTnProblem*)bp.take(sizeof(FcTnProblem) * w.max_probs);
@@ -569,11 +569,12 @@ int Ctx::note_ln(float* partial, float* dg, float* db, int M, int D) const {
   if (rec) rec->ln.push_back(LnNote{partial, dg, db, M, D});
   for (FcLnReduce& e : *lnq)
     if (e.dg == dg) {
-      FC_REQUIRE(!e.partial2, "internal: more than two partial sets for one LayerNorm gradient");
-      e.partial2 = partial; e.nblocks2 = fc_layernorm_bwd_partial_blocks(M);
+      if (!e.partial2) { e.partial2 = partial; e.nblocks2 = fc_layernorm_bwd_partial_blocks(M); return 0; }
+      FC_REQUIRE(!e.partial3, "internal: more than three partial sets for one LayerNorm gradient");
+      e.partial3 = partial; e.nblocks3 = fc_layernorm_bwd_partial_blocks(M);
       return 0;
     }
-  lnq->push_back(FcLnReduce{partial, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, ln_accumulate});
+  lnq->push_back(FcLnReduce{partial, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, ln_accumulate, nullptr, 0, 0});
   return 0;
 }
 
@@ -1104,8 +1105,9 @@ static int ensure_tables(const fc_model* m, const Ws& w, hipStream_t s, FcTnProb
 // ---- "streams" schedule (default): every tower, and every micro-batch slice of the image tower, is a CHAIN on its own stream; the
 // chains advance layer by layer (host enqueue order: layer-major, so no chain waits for another one's launches), each layer of each
 // chain being one replayed graph (run_layer).  Forward: three image slices (the weight-gradient stream is idle then) + the text tower;
-// backward: two image slices (57 : 43) + the text tower, the weight gradients of both towers queued per layer over the FULL batch by the
-// driver and flushed every few layers to the weight-gradient stream behind all chains.
+// backward: three image slices (the third on the text tower's stream) + the text tower on the weight-gradient stream, the weight gradients
+// of both towers queued per layer over the FULL batch by the driver and flushed every few layers to the weight-gradient stream behind
+// the chains that produced them; the last image chunk goes to a chain's stream that has fallen idle by then.
 struct ChainDef { hipStream_t s; Ws w; int tower; int b0; hipEvent_t join; };
 static int build_chains(const fc_model* m, const Ws& w, hipStream_t s, bool fwd, bool run0, bool run1, bool deferred, ChainDef* ch) {
   int n = 0;
@@ -1113,16 +1115,28 @@ static int build_chains(const fc_model* m, const Ws& w, hipStream_t s, bool fwd,
   if (run0) {
     int nimg = (m->dt == FC_BF16 && (fwd || deferred)) ? microbatches(m, B) : 1;
     static const int fwd_chains = fc_knob("FC_FWD_CHAINS", 3);
+    static const int bwd_chains = fc_knob("FC_BWD_CHAINS", 3);
     if (fwd && nimg == 2 && fwd_chains == 3 && B >= 24 && m->dws) nimg = 3;   // 4.79 -> 4.71 ms per ViT-S step (round 3)
-    hipStream_t st[3] = {s, m->mbs[0], m->dws};
-    hipEvent_t ev[3] = {nullptr, m->ev_mb_join[0], m->ev_dw_prev};
+    // Three image chains in the backward as well (thirds of the batch; FC_BWD_CHAINS=2, tools build: two chains cut 57 : 43): the third
+    // on the text tower's stream, the text tower on the weight-gradient stream, chunk by chunk between the image chunks (backward_impl).
+    // 4.51 -> 4.44 ms per ViT-S img+txt step on one box, 4.58 -> 4.49 on another (profiles/r03/bwd3.txt).  Only beside a text tower and
+    // for narrow models: image-only ViT-S clients (4.41 -> 4.45 ms), ViT-Tiny (2.69 -> 2.81) and the 768-wide img+txt model (12.54 ->
+    // 12.68) are faster with two backward chains.
+    const bool bwd3 = !fwd && nimg == 2 && bwd_chains == 3 && B >= 24 && m->dws && m->side && deferred && run1 && m->cfg.dim <= 512;
+    if (bwd3) nimg = 3;
+    hipStream_t st[3] = {s, m->mbs[0], bwd3 ? m->side : m->dws};
+    hipEvent_t ev[3] = {nullptr, m->ev_mb_join[0], bwd3 ? m->ev_join : m->ev_dw_prev};
     // cut points of the three forward chains in percent of the batch (FC_FWD_CUTS = "a,b", tools build; default thirds)
     static const int cut_a = [] { const char* e = fc_knob_str("FC_FWD_CUTS"); return e ? atoi(e) : 0; }();
     static const int cut_b = [] { const char* e = fc_knob_str("FC_FWD_CUTS"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
     auto cut3 = [&](int k) { return k <= 0 ? 0 : k >= 3 ? B : (cut_a > 0 && cut_b > cut_a && cut_b < 100) ? std::max(k, std::min(B - 3 + k, (B * (k == 1 ? cut_a : cut_b) + 50) / 100)) : B * k / 3; };
     for (int k = 0; k < nimg; ++k) {
       const int b0 = nimg == 3 ? cut3(k) : mb_begin(B, k, nimg), b1 = nimg == 3 ? cut3(k + 1) : mb_begin(B, k + 1, nimg);
-      ch[n++] = ChainDef{st[k], nimg == 1 ? w : slice_ws(m, w, 0, b0, b1 - b0, k < 2 ? k : 1, false), 0, b0, ev[k]};
+      ch[n++] = ChainDef{st[k], nimg == 1 ? w : slice_ws(m, w, 0, b0, b1 - b0, fwd ? (k < 2 ? k : 1) : k, false), 0, b0, ev[k]};
+    }
+    if (run1 && bwd3) {                        // the text tower on the weight-gradient stream
+      ch[n++] = ChainDef{m->dws, w, 1, 0, m->ev_mb_join[2]};
+      return n;
     }
   }
   if (run1) {
@@ -1248,7 +1262,7 @@ struct DwState {
 };
 // launch the problems queued since the last flush as one grouped GEMM on the dW stream, ordered after everything enqueued so
 // far on this tower's stream (their dY / X operands are complete by then)
-static int flush_dw(const Ctx& c, bool narrow = false) {      // narrow: 128x128 tiles for every problem (a short last chunk)
+static int flush_dw(const Ctx& c, bool narrow = false, hipStream_t target = nullptr) {   // narrow: 128x128 tiles for every problem; target: default the dW stream
   if (!c.defer || !c.dw) return 0;
   std::vector<FcTnProblem>& all = *c.defer;
   DwState& st = *c.dw;
@@ -1273,15 +1287,20 @@ static int flush_dw(const Ctx& c, bool narrow = false) {      // narrow: 128x128
   const void* tab = nullptr;
   FC_TRY(cached_table(all.data() + beg, n * sizeof(FcTnProblem), &tab));
   const FcTnProblem* chunk = (const FcTnProblem*)tab;
-  FC_CHECK_HIP(hipEventRecord(m->ev_dw_in, c.s));
-  FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in, 0));
+  const hipStream_t tgt = target ? target : m->dws;
+  if (c.s != tgt) {
+    FC_CHECK_HIP(hipEventRecord(m->ev_dw_in, c.s));
+    FC_CHECK_HIP(hipStreamWaitEvent(tgt, m->ev_dw_in, 0));
+  }
   for (int k = 0; k < c.n_more; ++k) {
-    FC_CHECK_HIP(hipEventRecord(m->ev_dw_in2[k], c.more_s ? c.more_s[k] : m->mbs[k]));
-    FC_CHECK_HIP(hipStreamWaitEvent(m->dws, m->ev_dw_in2[k], 0));
+    const hipStream_t ms = c.more_s ? c.more_s[k] : m->mbs[k];
+    if (ms == tgt) continue;
+    FC_CHECK_HIP(hipEventRecord(m->ev_dw_in2[k], ms));
+    FC_CHECK_HIP(hipStreamWaitEvent(tgt, m->ev_dw_in2[k], 0));
   }
   if (!FC_ABLATED("dw")) {
-    FC_TRY(fc_gemm_dw_wide(chunk, (int)nw, tiles_w, m->dws, c.fopt));
-    FC_TRY(fc_gemm_tn_grouped(chunk + nw, (int)(n - nw), tiles, m->dws, c.fopt));
+    FC_TRY(fc_gemm_dw_wide(chunk, (int)nw, tiles_w, tgt, c.fopt));
+    FC_TRY(fc_gemm_tn_grouped(chunk + nw, (int)(n - nw), tiles, tgt, c.fopt));
   }
   st.flushed = all.size();
   return 0;
@@ -1620,7 +1639,40 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     int kt = -1;
     for (int k = 0; k < n; ++k)
       if (ch[k].tower == 1 && ch[k].s != s && deferred && text_first) kt = k;
+    // Three backward chains: the text tower shares the weight-gradient stream, so its layers are enqueued chunk by chunk BETWEEN the
+    // image chunks -- [text layers of chunk 1][text chunk][image chunk 1][text layers of chunk 2] ... -- instead of all of it first: the
+    // image chunk of a group of layers then starts when those layers are done, not after the whole text backward.
+    const bool interleave = kt >= 0 && ch[kt].s == m->dws;
+    bool image_done = false;
     if (kt >= 0) {
+      nextra = 0;                                        // the image chunks wait for the image chains only
+      for (int k = 0; k < n; ++k)
+        if (k != kt && ch[k].s != s) extra[nextra++] = ch[k].s;
+    }
+    if (interleave) {
+      Ctx ct = c;
+      ct.s = ch[kt].s;
+      ct.n_more = 0;
+      cf_.n_more = nextra;
+      for (int l_hi = cf.depth - 1; l_hi >= 0;) {
+        int l_lo = l_hi;
+        while (l_lo > 0 && !dw_flush_here(l_lo)) --l_lo;
+        for (int l = l_hi; l >= l_lo; --l) {
+          FC_TRY(layer(kt, l));
+          FC_TRY(tower_backward(ct, w, 1, d_out_txt, grads, PH_WGRAD_LAYER, l));
+        }
+        if (l_lo == 0) FC_TRY(tower_backward(cx[kt], ch[kt].w, 1, d_out_txt, grads, PH_EMBED));
+        FC_TRY(flush_dw(ct));
+        for (int l = l_hi; l >= l_lo; --l) {
+          for (int k = 0; k < n; ++k)
+            if (k != kt) FC_TRY(layer(k, l));
+          if (run0) FC_TRY(tower_backward(cf_, w, 0, d_out_img, grads, PH_WGRAD_LAYER, l));
+        }
+        if (l_lo > 0) FC_TRY(flush_dw(cf_));             // the last image chunk follows the embedding backward below
+        l_hi = l_lo - 1;
+      }
+      image_done = true;
+    } else if (kt >= 0) {
       Ctx ct = c;
       ct.s = ch[kt].s;
       for (int l = cf.depth - 1; l >= 0; --l) {
@@ -1630,12 +1682,9 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
       }
       FC_TRY(tower_backward(cx[kt], ch[kt].w, 1, d_out_txt, grads, PH_EMBED));
       FC_TRY(flush_dw(ct));
-      nextra = 0;                                        // the image chunks wait for the image chains only
-      for (int k = 0; k < n; ++k)
-        if (k != kt && ch[k].s != s) extra[nextra++] = ch[k].s;
       cf_.n_more = nextra;
     }
-    for (int l = cf.depth - 1; l >= 0; --l) {
+    for (int l = cf.depth - 1; l >= 0 && !image_done; --l) {
       for (int k = 0; k < n; ++k)
         if (k != kt) FC_TRY(layer(k, l));
       if (deferred) {
@@ -1674,7 +1723,14 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
       // "6,2" narrow 4.77-4.78, "6,1" narrow 4.81, "7,3" narrow 4.80, narrow alone 4.91; profiles/r03/dw_tail_ab.txt): the extra middle
       // chunk competes with the chains for CUs and costs more than the shorter tail returns.
       static const bool last_narrow = fc_knob("FC_DW_LAST_NARROW", 0) != 0;
-      FC_TRY(flush_dw(cf_, last_narrow));
+      // three backward chains: the weight-gradient stream still carries the text tower's backward and the earlier chunks when the image
+      // chains end, and their own streams fall idle -- the last chunk goes to the first extra image chain's stream (FC_DW_LAST_ON=0: dW stream)
+      hipStream_t last_on = nullptr;
+      static const int last_knob = fc_knob("FC_DW_LAST_ON", 1);
+      if (kt >= 0 && ch[kt].s == m->dws && last_knob)
+        for (int k = 0; k < n && !last_on; ++k)
+          if (ch[k].tower == 0 && ch[k].s != s) last_on = ch[k].s;
+      FC_TRY(flush_dw(cf_, last_narrow, last_on));
     }
     FC_STREAM_EV(3, m->side); FC_STREAM_EV(4, m->mbs[0]); FC_STREAM_EV(5, s);
     FC_TRY(chains_join(s, ch, n));
