@@ -63,13 +63,11 @@ def kernel_source_stamp():
 
 
 # The dominant kernel of the step (profiles/: largest share of kernel time): the NN dX GEMM k_gemm_mfma<KC,KR,bf16,PLAIN>, at the
-# shape the model launches it with most FLOPs: dh2 = gdu . W1 of the FIRST image micro-batch chain of the default schedule (57 % of
-# the B = 64 batch: 36 samples x 197 rows; the library's mb_begin() rule), N = 384, K = 1536.
-MB_FIRST_PCT = 57
-
-
+# shape the model launches it with most FLOPs: dh2 = gdu . W1 of the LARGEST backward image chain of the default schedule (three chains
+# cut at B k / 3, the library's build_chains() rule: 21 + 21 + 22 samples of the B = 64 batch -> 22 x 197 rows), N = 384, K = 1536.
 def roof_shape(B=64):
-    return 1, (B * MB_FIRST_PCT // 100) * 197, 384, 1536
+    largest = max(B * (k + 1) // 3 - B * k // 3 for k in range(3))
+    return 1, largest * 197, 384, 1536
 
 
 ROOF_KIND, ROOF_M, ROOF_N, ROOF_K = roof_shape()
@@ -109,7 +107,7 @@ def gemm_roofline(steps=200):
             traffic = rec.get("hbm_bytes_per_launch")
         else:
             note = "profiles/r03/roofline_pmc.json was measured on other kernel sources / another shape: traffic withheld (re-run tools/collect_profiles.sh)"
-    out = dict(bound="mfma", kernel=f"k_gemm_mfma<KC,KR,bf16,PLAIN> (NN dX GEMM: dh2 = gdu.W1 of the first image micro-batch chain) {M}x{N}x{K} bf16",
+    out = dict(bound="mfma", kernel=f"k_gemm_mfma<KC,KR,bf16,PLAIN> (NN dX GEMM: dh2 = gdu.W1 of the largest backward image chain) {M}x{N}x{K} bf16",
                achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
                traffic=traffic, us_per_launch=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
                algorithmic_bytes_per_launch=alg_bytes, hbm_frac=round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))

@@ -1127,8 +1127,11 @@ static int build_chains(const fc_model* m, const Ws& w, hipStream_t s, bool fwd,
     hipStream_t st[3] = {s, m->mbs[0], bwd3 ? m->side : m->dws};
     hipEvent_t ev[3] = {nullptr, m->ev_mb_join[0], bwd3 ? m->ev_join : m->ev_dw_prev};
     // cut points of the three forward chains in percent of the batch (FC_FWD_CUTS = "a,b", tools build; default thirds)
-    static const int cut_a = [] { const char* e = fc_knob_str("FC_FWD_CUTS"); return e ? atoi(e) : 0; }();
-    static const int cut_b = [] { const char* e = fc_knob_str("FC_FWD_CUTS"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
+    static const int fcut_a = [] { const char* e = fc_knob_str("FC_FWD_CUTS"); return e ? atoi(e) : 0; }();
+    static const int fcut_b = [] { const char* e = fc_knob_str("FC_FWD_CUTS"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
+    static const int bcut_a = [] { const char* e = fc_knob_str("FC_BWD_CUTS"); return e ? atoi(e) : 0; }();
+    static const int bcut_b = [] { const char* e = fc_knob_str("FC_BWD_CUTS"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
+    const int cut_a = fwd ? fcut_a : bcut_a, cut_b = fwd ? fcut_b : bcut_b;
     auto cut3 = [&](int k) { return k <= 0 ? 0 : k >= 3 ? B : (cut_a > 0 && cut_b > cut_a && cut_b < 100) ? std::max(k, std::min(B - 3 + k, (B * (k == 1 ? cut_a : cut_b) + 50) / 100)) : B * k / 3; };
     for (int k = 0; k < nimg; ++k) {
       const int b0 = nimg == 3 ? cut3(k) : mb_begin(B, k, nimg), b1 = nimg == 3 ? cut3(k + 1) : mb_begin(B, k + 1, nimg);

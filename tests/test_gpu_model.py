@@ -125,8 +125,9 @@ def test_errors_are_loud():
 @pytest.mark.parametrize("kind", ["img+txt", "img"])
 def test_microbatch_chains_do_not_change_the_result(tmp_path, kind, B):
     """The image tower runs as micro-batch chains by default (FC_MICROBATCH, read once per process), with or without a text tower
-    beside it: an odd batch (B = 17 -> 10 + 7 in both directions; B = 25 / 37 -> three forward chains cut at B/3, 2B/3 and two
-    backward chains cut at 57 %) gives the same gradients as the single-chain run up to the order of the LayerNorm partial sums.
+    beside it: an odd batch (B = 17 -> 10 + 7 in both directions; B = 25 / 37 -> three forward chains cut at B/3, 2B/3 and, beside a text
+    tower, three backward chains with the text tower on the weight-gradient stream -- two backward chains cut at 57 % for the image-only
+    client) gives the same gradients as the single-chain run up to the order of the LayerNorm partial sums.
     'img' = an image classifier with trained re-param linears (its head's weight gradients are taken for the full batch before the
     chains fork)."""
     import os

@@ -51,12 +51,13 @@ if [ -f fedcola_amd/libfedcola_hip_probes.so ]; then
   ms() { grep -o '"ms_per_step": [0-9.]*' | tr '\n' ' '; }
   { echo "# ms per step, tools build, same box, two passes each (bench.py --steps 100 --warmup 10)"
     for i in 1 2; do
-      echo "streams (product default: 3 image chains forward, text first backward)  $(FC_PROBES_LIB=1 timeout 200 $B2 2>/dev/null | ms)"
+      echo "streams (product default: 3 image chains forward and backward, text on dW)  $(FC_PROBES_LIB=1 timeout 200 $B2 2>/dev/null | ms)"
+      echo "streams with 2 backward chains 57:43, text on its own stream (FC_BWD_CHAINS=2) $(FC_PROBES_LIB=1 FC_BWD_CHAINS=2 timeout 200 $B2 2>/dev/null | ms)"
       echo "streams + per-layer HIP graphs (FC_GRAPHS=1)                            $(FC_PROBES_LIB=1 FC_GRAPHS=1 timeout 200 $B2 2>/dev/null | ms)"
       echo "one chain of grouped launches (FC_SCHEDULE=chain)                       $(FC_PROBES_LIB=1 FC_SCHEDULE=chain timeout 200 $B2 2>/dev/null | ms)"
       echo "two chains of grouped launches (FC_SCHEDULE=chain2)                     $(FC_PROBES_LIB=1 FC_SCHEDULE=chain2 timeout 200 $B2 2>/dev/null | ms)"
       echo "2 forward chains (FC_FWD_CHAINS=2)                                      $(FC_PROBES_LIB=1 FC_FWD_CHAINS=2 timeout 200 $B2 2>/dev/null | ms)"
-      echo "text tower last in the backward (FC_TEXT_FIRST=0)                       $(FC_PROBES_LIB=1 FC_TEXT_FIRST=0 timeout 200 $B2 2>/dev/null | ms)"
+      echo "2 backward chains, text tower last (FC_BWD_CHAINS=2 FC_TEXT_FIRST=0)    $(FC_PROBES_LIB=1 FC_BWD_CHAINS=2 FC_TEXT_FIRST=0 timeout 200 $B2 2>/dev/null | ms)"
     done; } > "$OUT/schedules_ab.txt"
   for sch in streams chain; do FC_PROBES_LIB=1 FC_SCHEDULE=$sch timeout 200 python tools/step_phases.py 40 2>/dev/null > "$OUT/step_phases_$sch.txt"; done
   timeout 300 python tools/gemm_big_bench.py 20 2>/dev/null > "$OUT/gemm_big_bench.txt"
