@@ -1116,7 +1116,8 @@ static int build_chains(const fc_model* m, const Ws& w, hipStream_t s, bool fwd,
     int nimg = (m->dt == FC_BF16 && (fwd || deferred)) ? microbatches(m, B) : 1;
     static const int fwd_chains = fc_knob("FC_FWD_CHAINS", 3);
     static const int bwd_chains = fc_knob("FC_BWD_CHAINS", 3);
-    if (fwd && nimg == 2 && fwd_chains == 3 && B >= 24 && m->dws) nimg = 3;   // 4.79 -> 4.71 ms per ViT-S step (round 3)
+    // 4.79 -> 4.71 ms per ViT-S step (round 3); the 768-wide model is faster with two forward chains (12.63 vs 12.84 ms)
+    if (fwd && nimg == 2 && fwd_chains == 3 && B >= 24 && m->dws && m->cfg.dim <= 512) nimg = 3;
     // Three image chains in the backward as well (thirds of the batch; FC_BWD_CHAINS=2, tools build: two chains cut 57 : 43): the third
     // on the text tower's stream, the text tower on the weight-gradient stream, chunk by chunk between the image chunks (backward_impl).
     // 4.51 -> 4.44 ms per ViT-S img+txt step on one box, 4.58 -> 4.49 on another (profiles/r03/bwd3.txt).  Only beside a text tower and
