@@ -113,6 +113,23 @@ def gemm_roofline(steps=200):
                algorithmic_bytes_per_launch=alg_bytes, hbm_frac=round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
     if note:
         out["traffic_note"] = note
+    # the same kernel over the whole batch's rows (how the one-chain schedule launches it): a third of the batch fills 102 tiles on 256
+    # CUs, so the in-model figure above is the tile count's, not the main loop's
+    Mf = 64 * 197
+    Af = torch.randn(Mf, K, device="cuda").bfloat16()
+    Cf = torch.empty(Mf, N, device="cuda", dtype=torch.bfloat16)
+    with torch.cuda.stream(st):
+        for _ in range(10):
+            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(Af), P(W), P(Cf), Mf, N, K, None, 0, sp))
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(st)
+        for _ in range(steps):
+            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(Af), P(W), P(Cf), Mf, N, K, None, 0, sp))
+        f1.record(st)
+    f1.synchronize()
+    msf = f0.elapsed_time(f1) / steps
+    af = 2.0 * Mf * N * K / (msf * 1e-3) / 1e12
+    out["full_batch_rows"] = dict(shape=f"{Mf}x{N}x{K}", us_per_launch=round(msf * 1e3, 2), achieved=round(af, 2), frac=round(af / PEAK_BF16_TFLOPS, 4))
     return out
 
 
