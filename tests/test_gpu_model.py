@@ -186,9 +186,11 @@ def test_fused_optimizer_is_bit_identical_to_the_separate_one(tmp_path, kind, wi
     assert n_lin > 0.8 * out["0"]["p"].numel()
 
 
-def test_colearn_attn_d384_bf16_shared_attention_gradients():
+@pytest.mark.parametrize("B", [8, 32])
+def test_colearn_attn_d384_bf16_shared_attention_gradients(B):
     """colearn_param == 'attn' at the ViT-S width in the timed mode: the text tower's weight gradients of the shared qkv / proj go
-    through the 128x384 grouped kernel into the side buffer and are added to the image tower's; against the emulating oracle."""
+    through the 128x384 grouped kernel into the side buffer and are added to the image tower's; against the emulating oracle.
+    B = 8: one image chain; B = 32: three image chains in both directions with the text tower on the weight-gradient stream."""
     from fedcola_amd.mome import ModalityAgnosticTransformer as M
     from synth import det_state_dict
     mk = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=384, depth=2, num_heads=6,
@@ -197,7 +199,7 @@ def test_colearn_attn_d384_bf16_shared_attention_gradients():
     torch.manual_seed(3)
     ref = M(**mk)
     sd = {k: v.clone() for k, v in ref.state_dict().items()}
-    B, seq = 8, 16
+    seq = 16
     g = torch.Generator().manual_seed(21)
     img = (torch.randn(B, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1)
     ids = torch.randint(1, 97, (B, seq), generator=g)
