@@ -148,13 +148,15 @@ def test_microbatch_chains_do_not_change_the_result(tmp_path, kind, B):
         assert float((out["1"][k] - out["2"][k]).abs().max()) <= 2e-5 * scale, k
 
 
-@pytest.mark.parametrize("kind,width,dw_wide", [("img+txt", 128, "2"), ("img", 128, "2"), ("img+txt", 384, "2"), ("img+txt", 384, "1")])
-def test_fused_optimizer_is_bit_identical_to_the_separate_one(tmp_path, kind, width, dw_wide):
+@pytest.mark.parametrize("kind,width,dw_wide,B", [("img+txt", 128, "2", 0), ("img", 128, "2", 0), ("img+txt", 384, "2", 0), ("img+txt", 384, "1", 0),
+                                                  ("img+txt", 384, "2", 32)])
+def test_fused_optimizer_is_bit_identical_to_the_separate_one(tmp_path, kind, width, dw_wide, B):
     """fc_client_step takes the AdamW step of the linears inside the weight-gradient GEMM's epilogue (FC_FUSED_OPT, tools build, read
     once per process, default on).  One step with weight decay from non-trivial moments: the linears' parameters, both moments, bf16
     compute weights and gradients are the same BITS as with the separate optimizer pass.  Width 128: the 128x128-tile grouped kernel;
     width 384 (depth 2, B = 16, two chains): the wide 128x384-tile kernels of the ViT-S / ViT-B steps, in both of their forms
-    (FC_DW_WIDE = 2: 8 consumer + 2 loader waves, the default; 1: 8 waves)."""
+    (FC_DW_WIDE = 2: 8 consumer + 2 loader waves, the default; 1: 8 waves).  B = 32: three image chains in both directions, text tower on the
+    weight-gradient stream, the last chunk on a chain's stream -- the separate optimizer's two phases around that chunk included."""
     import os
     import subprocess
     import sys
@@ -165,8 +167,8 @@ def test_fused_optimizer_is_bit_identical_to_the_separate_one(tmp_path, kind, wi
     for fused in ("0", "1"):
         f = str(tmp_path / f"f{fused}.pt")
         env = dict(os.environ, FC_FUSED_OPT=fused, FC_PROBES_LIB="1", FC_DW_WIDE=dw_wide)
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "opt_check.py"), kind, f, str(width)], env=env, capture_output=True, text=True,
-                           timeout=300)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "opt_check.py"), kind, f, str(width)] + ([str(B)] if B else []), env=env,
+                           capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         out[fused] = torch.load(f)
     assert abs(out["0"]["loss"] - out["1"]["loss"]) <= 1e-5          # the loss sum is atomic: equal up to its order

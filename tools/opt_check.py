@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Fused-optimizer check (development aid + tests/test_gpu_model.py): one bf16 client step with FC_FUSED_OPT from the env; saves the
-parameters, both moments, the bf16 compute weights and the last gradients.  usage: opt_check.py img+txt|img OUT.pt [width=128]
+parameters, both moments, the bf16 compute weights and the last gradients.  usage: opt_check.py img+txt|img OUT.pt [width=128] [B]
 width 128: every layer linear takes the 128x128-tile grouped kernel; width 384 (depth 2, B = 16: two micro-batch chains): the wide
 128x384-tile kernels the ViT-S / ViT-B steps use (FC_DW_WIDE = 1 | 2 selects their two forms)."""
 import os, sys
@@ -20,7 +20,7 @@ else:
     mk = dict(modalities=["img", None], num_classes=[10, None], tasks=["cls", None], **common)
 torch.manual_seed(0)
 sd = det_state_dict({k: tuple(v.shape) for k, v in M(**mk).state_dict().items()}, base_seed=5)
-B = 12 if width == 128 else 16
+B = int(sys.argv[4]) if len(sys.argv) > 4 else (12 if width == 128 else 16)      # B >= 24 beside a text tower: three chains in both directions
 g = torch.Generator().manual_seed(3)
 img = (torch.randn(B, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1)
 ids = torch.randint(1, 64, (B, 16), generator=g)
