@@ -145,7 +145,12 @@ def test_microbatch_chains_do_not_change_the_result(tmp_path, kind, B):
         out[mb] = torch.load(f)
     for k in out["1"]:
         scale = max(float(out["1"][k].abs().max()), 1e-9)
-        assert float((out["1"][k] - out["2"][k]).abs().max()) <= 2e-5 * scale, k
+        err = float((out["1"][k] - out["2"][k]).abs().max())
+        # weight matrices come from full-batch weight-gradient problems in either schedule; vectors (bias / LayerNorm: column sums whose
+        # partial rows are grouped per chain) and embedding tables (atomic adds) differ by their fp32 summation order, which for a
+        # cancelling sum reaches a few 1e-5 of the maximum (one run in eight crossed 2e-5)
+        tol = 2e-5 if (out["1"][k].dim() > 1 and "embeddings" not in k) else 2e-4
+        assert err <= tol * scale, (k, err / scale)
 
 
 @pytest.mark.parametrize("kind,width,dw_wide,B", [("img+txt", 128, "2", 0), ("img", 128, "2", 0), ("img+txt", 384, "2", 0), ("img+txt", 384, "1", 0),
