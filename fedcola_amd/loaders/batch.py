@@ -130,21 +130,23 @@ class _BatchIter:
         list(pool.map(lambda ch: ld._fill_chunk(bufs, ch[0], ch[1]), chunks))
         return tuple(bufs)
 
+    def _put(self, item):
+        while not self.stop.is_set():   # never blocks for good: an abandoned epoch (close()) lets the thread end
+            try:
+                self.q.put(item, timeout=0.05)
+                return
+            except queue.Full:
+                pass
+
     def _produce(self):
         try:
             for idxs in self.batches:
                 if self.stop.is_set():
                     return
-                item = self._assemble(idxs)
-                while not self.stop.is_set():
-                    try:
-                        self.q.put(item, timeout=0.05)
-                        break
-                    except queue.Full:
-                        pass
-            self.q.put(None)
+                self._put(self._assemble(idxs))
+            self._put(None)
         except BaseException as e:      # surfaces in the consumer
-            self.q.put(e)
+            self._put(e)
 
     def __iter__(self):
         return self
