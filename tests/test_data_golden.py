@@ -187,6 +187,46 @@ def test_pinned_batch_loader_yields_the_dataloaders_batches():
             assert x.dtype == y.dtype and torch.equal(x, y)
 
 
+def test_batch_iterator_draws_its_rng_numbers_when_created_and_can_be_abandoned():
+    """The epoch iterator is an object: the sampler's RNG draws happen when iter() is CALLED (FedavgClient.update() creates it before it
+    allocates the optimizer state so that the first batch is assembled meanwhile), not at the first next(); an abandoned epoch ends its
+    producer thread on close(); an exhausted iterator stays exhausted."""
+    import threading
+    import time
+    from fedcola_amd.loaders.batch import PinnedBatchLoader
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            return torch.full((2, 3), float(i)), i
+
+    torch.manual_seed(11)
+    ref = list(torch.utils.data.DataLoader(DS(), batch_size=6, shuffle=True))
+    ld = PinnedBatchLoader(DS(), 6, shuffle=True, workers=2)
+    torch.manual_seed(11)
+    it = iter(ld)
+    torch.manual_seed(999)                                   # whatever the caller does to the generator afterwards changes nothing
+    got = list(it)
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        for x, y in zip(a, b):
+            assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
+    with pytest.raises(StopIteration):
+        next(it)
+    base = threading.active_count()
+    it2 = iter(ld)
+    next(it2)
+    assert threading.active_count() == base + 1              # the producer of the open epoch
+    it2.close()
+    for _ in range(50):
+        if threading.active_count() == base:
+            break
+        time.sleep(0.02)
+    assert threading.active_count() == base
+
+
 # ---------------------------------------------------------------------------------------------- tokenizer (data.py:182-190)
 def test_bert_vocab_tokenizer_matches_hf_golden_ids():
     import json
