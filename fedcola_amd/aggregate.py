@@ -225,7 +225,7 @@ def hip_local_partial(plan: BlendPlan, global_flat: torch.Tensor, local_flats: M
     from . import _lib
     from ._lib import check, ptr
     if len(plan.ids) > 64:
-        return _hip_local_partial_many(plan, global_flat, local_flats, include_global)
+        return _hip_local_partial_many(plan, global_flat, local_flats, include_global, out)
     t = _device_tables(plan, global_flat.device, set(local_flats.keys()), include_global)
     if out is None:
         out = torch.zeros_like(global_flat)
@@ -234,14 +234,16 @@ def hip_local_partial(plan: BlendPlan, global_flat: torch.Tensor, local_flats: M
     return out
 
 
-def _hip_local_partial_many(plan, global_flat, local_flats, include_global):
-    """More than 64 sampled clients: the client pointers go through a device table (fc_aggregate_blend)."""
+def _hip_local_partial_many(plan, global_flat, local_flats, include_global, out=None):
+    """More than 64 sampled clients: the client pointers go through a device table (fc_aggregate_blend).  Writes `out` when given
+    (aggregate_many hands in its slice of the concatenated all-reduce buffer)."""
     from . import _lib
     from ._lib import check, ptr
     dev = global_flat.device
     t = _device_tables(plan, dev, set(local_flats.keys()), include_global)
     bases = torch.tensor([local_flats[i].data_ptr() if i in local_flats else 0 for i in plan.ids], dtype=torch.int64).to(dev)
-    out = torch.zeros_like(global_flat)
+    if out is None:
+        out = torch.zeros_like(global_flat)
     check(_lib.lib().fc_aggregate_blend(ptr(out), ptr(global_flat), ptr(bases), len(plan.ids), ptr(t["seg_off"]), ptr(t["seg_len"]), ptr(t["src"]),
                                         ptr(t["w"]), len(plan.keys), _lib.stream_ptr()))
     torch.cuda.current_stream().synchronize()          # `bases` is a temporary
@@ -319,7 +321,9 @@ def aggregate_many(items, *, rank: int = 0, world: int = 1, all_reduce: Optional
     for gm, plan, flats in items:
         n = gm.flat.numel()
         if local_partial is None:
-            hip_local_partial(plan, gm.flat.data, flats, include_global=(rank == 0), out=cat[off:off + n])
+            part = hip_local_partial(plan, gm.flat.data, flats, include_global=(rank == 0), out=cat[off:off + n])
+            if part.data_ptr() != cat[off:off + n].data_ptr():      # a path that ignored `out` must not leave the slice stale
+                cat[off:off + n].copy_(part)
         else:
             cat[off:off + n].copy_(local_partial(plan, gm.flat.data, flats, include_global=(rank == 0)))
         views.append((gm, plan, cat[off:off + n]))

@@ -49,6 +49,8 @@ class Comm:
         import hashlib
         if nonce is None:
             nonce = os.environ.get("FC_JOB_NONCE") or f'{os.environ.get("MASTER_ADDR", "")}:{os.environ.get("MASTER_PORT", "")}'
+            if nonce == ":":            # nothing identifies this job: a stale file of a crashed one would be accepted as ours
+                raise ValueError("Comm.from_file needs a job nonce: pass nonce=, or set FC_JOB_NONCE or MASTER_ADDR / MASTER_PORT")
         tag = hashlib.sha256(nonce.encode()).digest()[:16]
         if rank == 0:
             try:

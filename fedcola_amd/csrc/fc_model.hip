@@ -7,6 +7,7 @@
 #include <string>
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -66,7 +67,7 @@ struct fc_model {
   mutable std::vector<std::pair<int64_t, int64_t>> zero_runs;   // fc_client_step: (offset, count) runs of the gradient buffer that must be zeroed
   mutable int cover_B = -1, cover_ntxt = -1;
   mutable std::vector<char> fused_host, rest_host;
-  mutable void* rest_dev = nullptr;
+  mutable bool rest_valid = false;                // rest_host / rest_chunks describe fused_host
   mutable int rest_chunks = 0;
   // the two towers are independent until the loss: the text tower runs on a side stream, forked/joined with events
   mutable hipStream_t side = nullptr;
@@ -787,17 +788,26 @@ static int g_stream_step = 0;
 // tables meant an allocation, an upload from pageable memory (which blocks the host until the stream gets there: 2.6 ms of the first
 // step of every round) and, on replacement, a device synchronisation.  A table that is found here costs nothing; a new one costs one
 // allocation + one synchronous copy, once per process.
+// Lifetime rule: a pointer returned here is valid until the caller's NEXT cached_table() call at the latest (the cache may start over
+// inside any call, behind a device synchronisation, so kernels already enqueued with an old table have finished before it is freed).
+// Nobody keeps such a pointer across calls -- a handle that needs its table again asks again (a hit is one map lookup).
+static std::mutex g_table_mu;
 static int cached_table(const void* host, size_t bytes, const void** out) {
   static std::map<std::string, void*> cache;
+  static const size_t limit = (size_t)fc_knob("FC_TABLE_CACHE_MAX", 1024);     // (tools build: a small limit forces the start-over path)
+  std::lock_guard<std::mutex> lock(g_table_mu);
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::string key((const char*)&dev, sizeof(dev));
   key.append((const char*)host, bytes);
   auto it = cache.find(key);
   if (it != cache.end()) { *out = it->second; return 0; }
-  if (cache.size() >= 1024) {                     // addresses kept changing: start over (nothing may still read the old tables)
-    FC_CHECK_HIP(hipDeviceSynchronize());
-    for (auto& kv : cache) (void)hipFree(kv.second);
+  if (cache.size() >= limit) {                    // addresses kept changing: start over.  The tables of the generation BEFORE this one are
+    static std::vector<void*> retired;            // freed now, behind a device synchronisation; this generation's stay allocated until the
+    FC_CHECK_HIP(hipDeviceSynchronize());         // next start-over, so a thread that has just been handed one can still launch with it
+    for (void* q : retired) (void)hipFree(q);
+    retired.clear();
+    for (auto& kv : cache) retired.push_back(kv.second);
     cache.clear();
   }
   void* d = nullptr;
@@ -1799,7 +1809,7 @@ extern "C" int fc_ce_loss_fwd_bwd(const float* logits, const int64_t* y, int32_t
 // AdamW of every trainable segment the fused weight-gradient epilogue did NOT step (flag 0 in `fused`), as one chunked launch.  The
 // chunk table depends only on the model and on which problems took the grouped path, so it is built once and kept in the handle.
 static int adamw_rest(const fc_model* m, const std::vector<char>& fused, const FcAdamW& o, hipStream_t s) {
-  if (m->fused_host != fused || !m->rest_dev) {
+  if (m->fused_host != fused || !m->rest_valid) {
     std::vector<FcProxChunk> ch;
     int64_t beg = -1, end = -1;
     auto cut = [&]() {
@@ -1815,16 +1825,16 @@ static int adamw_rest(const fc_model* m, const std::vector<char>& fused, const F
       end = sg.offset + sg.numel;
     }
     cut();
-    m->rest_dev = nullptr;
+    m->rest_host.assign((const char*)ch.data(), (const char*)ch.data() + ch.size() * sizeof(FcProxChunk));
     m->rest_chunks = (int)ch.size();
-    if (!ch.empty()) {
-      const void* t = nullptr;
-      FC_TRY(cached_table(ch.data(), ch.size() * sizeof(FcProxChunk), &t));
-      m->rest_dev = (void*)t;
-    }
     m->fused_host = fused;
+    m->rest_valid = true;
   }
-  return fc_adamw_chunks((const FcProxChunk*)m->rest_dev, m->rest_chunks, o, s);
+  if (m->rest_chunks == 0) return 0;
+  // the device table is looked up on EVERY step: the cache owns it and may have started over since the last one (cached_table)
+  const void* t = nullptr;
+  FC_TRY(cached_table(m->rest_host.data(), m->rest_host.size(), &t));
+  return fc_adamw_chunks((const FcProxChunk*)t, m->rest_chunks, o, s);
 }
 static int adamw_ranges(const fc_model* m, float* p, float* g, float* mm, float* vv, float lr, float b1, float b2, float eps, float wd, int step,
                         hipStream_t s, bf16_t* shadow = nullptr, const std::vector<char>* late_seg = nullptr, int want_late = 0) {

@@ -157,7 +157,13 @@ class _BatchIter:
                 raise StopIteration
             self.pos += 1
             return self._assemble(self.batches[self.pos - 1])
-        item = self.q.get()
+        while True:                     # after close() the producer ends without a sentinel: never block on an abandoned epoch
+            try:
+                item = self.q.get(timeout=0.05)
+                break
+            except queue.Empty:
+                if self.stop.is_set() and (self.thread is None or not self.thread.is_alive()):
+                    raise StopIteration
         if item is None:
             self.q.put(None)            # stays exhausted
             raise StopIteration

@@ -325,7 +325,7 @@ class ModalityAgnosticTransformer(nn.Module):
         new = ModalityAgnosticTransformer.__new__(ModalityAgnosticTransformer)
         nn.Module.__init__(new)
         for k, v in self.__dict__.items():
-            if k in ("_parameters", "_buffers", "_modules", "_wc", "_ws", "_views", "_handle", "_dp_keep", "_agg_partial", "_client_owned"):
+            if k in ("_parameters", "_buffers", "_modules", "_wc", "_ws", "_views", "_handle", "_dp_keep", "_agg_partial", "_agg_cat", "_client_owned"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._handle = _Handle(self._handle.cfg)
@@ -354,7 +354,7 @@ class ModalityAgnosticTransformer(nn.Module):
         for k, s in src.segments.items():                                # freeze flags follow the source (as in __deepcopy__)
             if self.segments[k]["trainable"] != s["trainable"]:
                 self.set_trainable(k, s["trainable"])
-        skip = ("_parameters", "_buffers", "_modules", "_wc", "_ws", "_views", "_handle", "_dp_keep", "_agg_partial", "segments", "training",
+        skip = ("_parameters", "_buffers", "_modules", "_wc", "_ws", "_views", "_handle", "_dp_keep", "_agg_partial", "_agg_cat", "segments", "training",
                 "_wc_version", "_client_owned")
         for k, v in src.__dict__.items():                                # plain Python state (hyper-parameters, alias maps, rates)
             if k not in skip:

@@ -104,7 +104,7 @@ from fedcola_amd.comm import Comm
 rec = G.load("agg.json")[idx]
 res = {}
 try:
-    comm = Comm.from_file(idpath, rank, world)
+    comm = Comm.from_file(idpath, rank, world, nonce=idpath)       # the tmp path is unique per test run
 except Exception as e:
     json.dump({"skip": str(e)}, open(out, "w")); sys.exit(0)
 for mode in ("closed", "exact"):

@@ -193,6 +193,33 @@ def test_fused_optimizer_is_bit_identical_to_the_separate_one(tmp_path, kind, wi
     assert n_lin > 0.8 * out["0"]["p"].numel()
 
 
+def test_device_table_cache_survives_starting_over(tmp_path):
+    """The device tables of the grouped launches are cached per process by content and the cache starts over when it is full
+    (fc_model.hip::cached_table).  With a limit of 3 entries (FC_TABLE_CACHE_MAX, tools build) and batch sizes that keep changing the
+    cache starts over several times per run, also between a step's weight-gradient chunks and its optimizer remainder: no handle may
+    keep a cache-owned pointer across that (the optimizer's chunk table did).  Same parameters as with the default limit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "fedcola_amd", "libfedcola_hip_probes.so")):
+        pytest.skip("tools build (python -m fedcola_amd.build --probes) not present: the product library reads no tuning knobs")
+    out = {}
+    for lim in ("3", "1024"):
+        f = str(tmp_path / f"lim{lim}.pt")
+        env = dict(os.environ, FC_TABLE_CACHE_MAX=lim, FC_PROBES_LIB="1")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "table_cache_check.py"), f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[lim] = torch.load(f)
+    a, b = out["3"]["p"], out["1024"]["p"]
+    assert bool(torch.isfinite(a).all())
+    # eight AdamW steps of 1e-3: a parameter moves by <= 8e-3; run-to-run noise of the atomically summed embedding gradients can flip
+    # the sign of a step for near-zero gradients, a stale table corrupts whole chunks
+    assert float((a - b).abs().max()) <= 4e-3 and float((a - b).abs().mean()) <= 2e-5, (float((a - b).abs().max()), float((a - b).abs().mean()))
+    for x, y in zip(out["3"]["losses"], out["1024"]["losses"]):
+        assert abs(x - y) <= 2e-2 * max(1.0, abs(y))
+
+
 @pytest.mark.parametrize("B", [8, 32])
 def test_colearn_attn_d384_bf16_shared_attention_gradients(B):
     """colearn_param == 'attn' at the ViT-S width in the timed mode: the text tower's weight gradients of the shared qkv / proj go
