@@ -96,6 +96,7 @@ SIGNATURES = {
     "fc_k_layernorm_partial_floats": (_Z, [_I, _I]),
     "fc_k_layernorm_bwd_partial": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "fc_k_gemm": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "fc_k_gemm_epi": (C.c_int, [_I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "fc_k_attention_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fc_k_attention_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fc_k_dw": (C.c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),

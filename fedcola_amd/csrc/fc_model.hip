@@ -2207,6 +2207,19 @@ extern "C" int fc_k_layernorm_bwd_partial(int32_t dt, const void* dy, const void
   FC_CHECK_HIP(hipStreamSynchronize(s));      // `e` is a stack temporary (test entry point)
   return fc_ln_reduce_grouped(tab, 1, D, s);
 }
+// the bf16 MFMA GEMM with the epilogues the model uses (tools / tests): bias [+ residual] | bias + GELU with gelu'(u) saved | x mul_in
+extern "C" int fc_k_gemm_epi(int32_t kind, const void* A, const void* Bm, void* C, int32_t M, int32_t N, int32_t K, const float* bias, const void* res,
+                             void* gelu_grad_out, const void* mul_in, void* stream) {
+  GemmEpi e;
+  e.bias = bias; e.res = res;
+  if (gelu_grad_out) { e.preact = gelu_grad_out; e.gelu_saved_grad = 1; }
+  if (mul_in) { e.gelu_in = mul_in; e.gelu_saved_grad = 1; }
+  FC_REQUIRE(kind == FC_GEMM_NT || kind == FC_GEMM_NN, "fc_k_gemm_epi: kind must be NT (0) or NN (1)");
+  const long ldb = kind == FC_GEMM_NT ? K : N;
+  const int r = fc_gemm_mfma(kind, FC_BF16, (const bf16_t*)A, K, (const bf16_t*)Bm, ldb, C, N, M, N, K, e, (hipStream_t)stream);
+  FC_REQUIRE(r <= 0, "fc_k_gemm_epi: shape / alignment not covered by the MFMA kernel");
+  return r;
+}
 extern "C" int fc_k_gemm(int32_t impl, int32_t kind, int32_t dt_in, int32_t dt_out, const void* A, const void* Bm, void* C, int32_t M, int32_t N,
                          int32_t K, const float* bias, int32_t gelu, void* stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -252,6 +252,11 @@ int fc_k_layernorm_bwd_partial(int32_t dt, const void* dy, const void* x, const 
  * impl: 0 generic VALU, 1 MFMA bf16 (returns 1 when the shape is unsupported). dtC: type of C. bias may be NULL. */
 int fc_k_gemm(int32_t impl, int32_t kind, int32_t dt_in, int32_t dt_out, const void* A, const void* B, void* C, int32_t M,
               int32_t N, int32_t K, const float* bias, int32_t gelu, void* stream);
+/* the bf16 MFMA GEMM (kind 0 NT / 1 NN as above, bf16 in and out) with the fused epilogues of the model: C = A.B (+ bias) (+ res);
+ * gelu_grad_out != NULL: C = gelu(A.B + bias) and gelu'(A.B + bias) is stored to gelu_grad_out (fc1 forward, mome.py:117-123);
+ * mul_in != NULL: C = (A.B) * mul_in (the fc2 dX product times the saved gelu').  Unused pointers NULL. */
+int fc_k_gemm_epi(int32_t kind, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, const float* bias, const void* res,
+                  void* gelu_grad_out, const void* mul_in, void* stream);
 /* impl: 0 generic, 1 MFMA flash (bf16, d=64) */
 int fc_k_attention_fwd(int32_t impl, int32_t dt, const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H,
                        int32_t d, float scale, void* stream);
