@@ -145,7 +145,8 @@ def cpu_model_name():
 
 def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
     """Runs in a CHILD process (no GPU touched): the oracle's fp32 client step on the host cores.
-    1. sweep: one warm-up + one timed step at {32, 64, 128, all} threads (those <= the logical CPUs), for both forms of the step --
+    1. sweep: one warm-up + one timed step at {32, 16, 8} then {64, 128, all} threads (those <= the logical CPUs; each direction stops
+       once a setting is 1.25x slower than the best), explicit form; the autograd form at the best count --
        explicit backward (O.client_step) and torch.autograd over the same forward (O.client_step_autograd: what the reference's
        loss.backward() does); 2. `warm` warm-up + `timed` timed steps at the fastest (form, threads) -- cut short only by the budget."""
     import torch
@@ -174,15 +175,20 @@ def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
         forms[f](p, cfg, ("img+txt", img, ids), state[f], lr=1e-4)
         sweep[f"{f}@{t}"] = round(time.perf_counter() - t0, 3)
         return sweep[f"{f}@{t}"]
-    # thread counts in ascending order with the explicit form; stop when more threads are clearly slower or a third of the budget is
-    # gone (a 256-thread fp32 step can take 20 s on this host); then the autograd form at the best count
+    # thread counts with the explicit form: 32 first, then DOWNWARD (16, 8: torch's fp32 GEMMs at M = 12 608 stop scaling past a few dozen
+    # threads, SURVEY section 6 measured 22 pairs/s on 8 vCPUs) and upward (64, 128, all cores), each direction until a setting is
+    # 1.25x slower than the best so far or a third of the budget is gone (a 256-thread fp32 step can take 20 s on this host)
     best_t, best_s = None, None
-    for t in sorted({t for t in (32, 64, 128, cores) if 1 <= t <= cores} or {cores}):
-        sec = one("explicit", t)
-        if best_s is None or sec < best_s:
-            best_t, best_s = t, sec
-        if sec > 1.25 * best_s or time.perf_counter() - t_start > budget_s / 3:
-            break
+    start = min(32, cores)
+    for direction in ([start, 16, 8], [64, 128, cores]):
+        for t in direction:
+            if t < 1 or t > cores or f"explicit@{t}" in sweep:
+                continue
+            sec = one("explicit", t)
+            if best_s is None or sec < best_s:
+                best_t, best_s = t, sec
+            if sec > 1.25 * best_s or time.perf_counter() - t_start > budget_s / 3:
+                break
     one("autograd", best_t)
     best = min(sweep, key=sweep.get)
     form, threads = best.split("@")[0], int(best.split("@")[1])
@@ -204,7 +210,7 @@ def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
                                  f"{sweep}, {dt:.2f} s/step; host: {cpu_model_name()}, {os.cpu_count()} logical CPUs).  Both forms of the step "
                                  f"are timed (explicit backward / torch.autograd over the same forward, as the reference's loss.backward()) "
                                  f"and the faster is reported; the explicit form makes ~1.4x the elementwise passes and keeps every "
-                                 f"intermediate.  torch's fp32 CPU GEMMs at M = 12 608 stop scaling past a few dozen threads")), flush=True)
+                                 f"intermediate.  The sweep runs downward (16, 8) and upward (64, 128, all) from 32 threads")), flush=True)
 
 
 def cpu_baseline(B, seq, vocab, timeout=420):

@@ -102,6 +102,7 @@ SIGNATURES = {
     "fc_k_dw": (C.c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fc_k_adamw": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "fc_k_cast": (C.c_int, [_I, _P, _P, _L, _P]),
+    "fc_image_u8_to_f32": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "fc_retrieval_scratch_bytes": (C.c_size_t, [_I, _I]),
     "fc_retrieval_best_ranks": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, C.c_size_t, _P, _P]),
     "fc_k_sim_f64": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),

@@ -32,7 +32,7 @@ class FedavgClient(BaseClient):
         self.test_set = test_set
         self.optim = torch.optim.__dict__[self.args.optimizer]
         self.criterion = CRITERIA[criterion] if criterion in CRITERIA else torch.nn.__dict__[criterion]
-        self.train_loader = self._create_dataloader(self.training_set, shuffle=not self.args.no_shuffle)
+        self.train_loader = self._create_dataloader(self.training_set, shuffle=not self.args.no_shuffle, test=False)
         self.test_loader = self._create_dataloader(self.test_set, shuffle=False, test=True)
         self.task = task
         self.modality = modality
@@ -50,13 +50,23 @@ class FedavgClient(BaseClient):
         if self.args.B == 0:
             self.args.B = len(self.training_set)
         # device clients: same sampling as the DataLoader below, threaded assembly into pinned buffers (loaders/batch.py); the
-        # reference's single-process DataLoader (fedavgclient.py:44-53) needs 80-130 ms per B = 64 image batch on the MI355X host
-        # against a 5-ms device step.  Default only for datasets that declare themselves deterministic per index by offering
-        # get_batch() (in-memory / pre-decoded): worker threads would reorder the RNG draws of random-transform datasets.
-        # args.fast_loader = True / False overrides.
-        if getattr(self.args, "fast_loader", torch.cuda.is_available() and hasattr(dataset, "get_batch")):
+        # reference's single-process DataLoader (fedavgclient.py:44-53) needs 80-160 ms per B = 64 image batch on the MI355X host
+        # against a 4.5-ms device step.  Default for datasets that are a pure function of the index: those that offer get_batch()
+        # (in-memory / pre-decoded) and the caption datasets (Flickr30kCap / CocoCaptionsCap, also behind Subset wrappers) whose
+        # transform is deterministic -- the reference's --resize/--imnorm chain is -- which are decoded ONCE per client into a
+        # loaders.cache.DecodedCache (uint8 when lossless) and served from memory.  Random-transform datasets keep the DataLoader
+        # (worker threads would reorder their RNG draws).  args.fast_loader = True / False and args.decode_cache = False override.
+        from ..loaders.cache import DecodedCache
+        cuda = torch.cuda.is_available()
+        cacheable = getattr(self.args, "decode_cache", cuda) and not hasattr(dataset, "get_batch") and DecodedCache.applicable(dataset)
+        if getattr(self.args, "fast_loader", cuda and (hasattr(dataset, "get_batch") or cacheable)):
             from ..loaders.batch import PinnedBatchLoader
-            return PinnedBatchLoader(dataset, self.args.B, shuffle=shuffle, workers=getattr(self.args, "loader_workers", 8))
+            if cacheable:
+                dataset = DecodedCache(dataset, workers=getattr(self.args, "loader_workers", 8))      # built at its first batch
+            # the training loop reads its batches through DevicePrefetcher, which expands a cache's uint8 image codes on the device
+            # (loader.device_finish): the batch crosses PCIe as 9.6 MB instead of 38.5 MB and the host does no arithmetic
+            raw = cacheable and not test and cuda and getattr(self.args, "prefetch", True)
+            return PinnedBatchLoader(dataset, self.args.B, shuffle=shuffle, workers=getattr(self.args, "loader_workers", 8), raw=raw)
         return torch.utils.data.DataLoader(dataset=dataset, batch_size=self.args.B, shuffle=shuffle)
 
     # ------------------------------------------------------------------ the hot loop (fedavgclient.py:55-116)
@@ -193,6 +203,7 @@ class FedavgClient(BaseClient):
         model = self.model
         dev = model.flat.device
         optimizer = self.optim(model.parameters(), **oargs)
+        finish = getattr(self.train_loader, "device_finish", None)      # a raw loader's uint8 image codes -> floats (loaders/cache.py)
         for e in range(self.args.E):
             num = 0
             broke = False
@@ -201,6 +212,8 @@ class FedavgClient(BaseClient):
                     mm.aggregate(num * self.args.B, e + 1)
                     broke = True
                     break
+                if finish is not None and self.modality != "txt":
+                    batch = finish([batch[0].to(dev)] + list(batch[1:]))
                 model.flat.grad = None
                 if self.modality == "img+txt":
                     inputs, targets = batch[0].to(dev), batch[1].to(dev)

@@ -164,7 +164,7 @@ int fc_rowscale(int dt, const void* src, void* dst, const float* rs, int rows_pe
 }
 
 int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res,
-                     void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial, void* dx_scaled, const float* rowscale,
+                     void* dx, float* dg, float* db, int M, int D, hipStream_t s, fc_ln_part_t* partial, void* dx_scaled, const float* rowscale,
                      int rows_per_sample) {
   if (FC_ABLATED("ln")) return 0;
   if (M <= 0) return 0;
@@ -915,8 +915,52 @@ int fc_reparam_fold_grouped(int dt, const FcReparam* tab_dev, int nlin, const fl
   return 0;
 }
 
+// ======================================================================== pre-decoded image batches: uint8 -> the transform's float values
+// A client's decoded-image cache (fedcola_amd/loaders/cache.py) keeps images as uint8 codes with a per-channel table
+// lut[c][u] = Normalize(ToTensor(u)) (src/loaders/data.py:106-109 as torch ops): the batch crosses PCIe as uint8 (9.6 MB instead of
+// 38.5 MB at B = 64) and is expanded here, on the copy stream.  16 pixels per thread: one 16-byte load, four 16-byte stores.
+__global__ void __launch_bounds__(256) k_u8_lut(const uint8_t* __restrict__ src, const float* __restrict__ lut, float* __restrict__ dst, size_t n16,
+                                                int C, int HW16) {
+  __shared__ float tab[4 * 256];
+  for (int i = threadIdx.x; i < C * 256; i += 256) tab[i] = lut[i];
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i / HW16) % C);
+    const uint4 u = ((const uint4*)src)[i];
+    const float* t = tab + c * 256;
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      ((float4*)dst)[i * 4 + q] = make_float4(t[w[q] & 255], t[(w[q] >> 8) & 255], t[(w[q] >> 16) & 255], t[w[q] >> 24]);
+  }
+}
+__global__ void __launch_bounds__(256) k_u8_lut_s(const uint8_t* __restrict__ src, const float* __restrict__ lut, float* __restrict__ dst, size_t n, int C,
+                                                  int HW) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = lut[(int)((i / HW) % C) * 256 + src[i]];
+}
+extern "C" int fc_image_u8_to_f32(const uint8_t* src, const float* lut, float* dst, int64_t n_images, int32_t C, int32_t HW, void* stream) {
+  FC_REQUIRE(src && lut && dst, "fc_image_u8_to_f32: null buffer");
+  FC_REQUIRE(C >= 1 && C <= 4 && HW > 0 && n_images >= 0, "fc_image_u8_to_f32: bad geometry (channels %d, pixels %d)", C, HW);
+  const size_t n = (size_t)n_images * C * HW;
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if ((HW & 15) == 0 && !(((uintptr_t)src | (uintptr_t)dst) & 15)) {
+    const size_t n16 = n / 16;
+    const int grid = (int)((n16 + 255) / 256 > 2048 ? 2048 : (n16 + 255) / 256);
+    hipLaunchKernelGGL(k_u8_lut, dim3(grid), dim3(256), 0, s, src, lut, dst, n16, C, HW / 16);
+  } else {
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_u8_lut_s, dim3(grid), dim3(256), 0, s, src, lut, dst, n, C, HW);
+  }
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
 // ======================================================================== column sums (bias gradients)
-// grid: (ceil(N/64), row-chunks); each block sums 64 columns over its row chunk, 4 waves stride rows; atomics across chunks
+// fp32 input (the parity mode, and the fp32 classification heads of every mode): ONE block per 64 columns walks all rows, sums in
+// fp64 in a fixed order and stores once -- reproducible, and exact to the final fp32 rounding (these sums cancel to ~1e-3 of their
+// summands; an fp32 accumulation in any order costs ~1e-4 of the result there, which is the whole parity budget).
+// bf16 input (fallback paths only; the weight-gradient GEMMs produce the bias gradients of the timed mode): row chunks + atomics.
 template <typename T>
 __global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ dy, float* __restrict__ db, int M, int N, int rows_per_block) {
   __shared__ float red[4][64];
@@ -929,11 +973,32 @@ __global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ dy, float*
   __syncthreads();
   if (wave == 0 && col < N) atomicAdd(db + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+__global__ void __launch_bounds__(1024) k_colsum_f64(const float* __restrict__ dy, float* __restrict__ db, int M, int N, int accumulate) {
+  __shared__ double red[16][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (col < N)
+    for (int r = wave; r < M; r += 16) acc += (double)dy[(size_t)r * N + col];
+  red[wave][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (wave == 0 && col < N) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][threadIdx.x];
+    db[col] = accumulate ? (float)((double)db[col] + v) : (float)v;
+  }
+}
 int fc_colsum(int dt, const void* dy, float* db, int M, int N, int accumulate, hipStream_t s) {
+  if (dt == FC_F32) {
+    if (M <= 0) { if (!accumulate) FC_CHECK_HIP(hipMemsetAsync(db, 0, sizeof(float) * N, s)); return 0; }
+    hipLaunchKernelGGL(k_colsum_f64, dim3(fc_cdiv(N, 64)), dim3(1024), 0, s, (const float*)dy, db, M, N, accumulate);
+    FC_LAUNCH_CHECK();
+    return 0;
+  }
   if (!accumulate) FC_CHECK_HIP(hipMemsetAsync(db, 0, sizeof(float) * N, s));
   if (M <= 0) return 0;
   int rpb = 256;
-  DISPATCH_DT(dt, hipLaunchKernelGGL(k_colsum<T>, dim3(fc_cdiv(N, 64), fc_cdiv(M, rpb)), dim3(256), 0, s, (const T*)dy, db, M, N, rpb));
+  hipLaunchKernelGGL(k_colsum<bf16_t>, dim3(fc_cdiv(N, 64), fc_cdiv(M, rpb)), dim3(256), 0, s, (const bf16_t*)dy, db, M, N, rpb);
   FC_LAUNCH_CHECK();
   return 0;
 }

@@ -17,10 +17,14 @@ struct FcLnFwdP { const void* x; void* y; const float* g; const float* b; float*
 struct FcLnFwdArgs { FcLnFwdP p[2]; int nprob; int D; float eps; };
 // dx = (res ? res : 0) + LNbwd(dy); dx_scaled (optional): a second output dx * rowscale[row / rows_per_sample] (drop-path: the next
 // consumer's operand); partial: room for fc_layernorm_bwd_partial_blocks(M) * 2 * D floats, one [dgamma | dbeta] row per block, summed
-// later by fc_ln_reduce_grouped over the queued FcLnReduce entries
+// later by fc_ln_reduce_grouped over the queued FcLnReduce entries (room for ... * 2 * D fc_ln_part_t)
+// The [dgamma | dbeta] partial rows are DOUBLES: products d * xhat are formed in fp32 (as the reference does) and summed in fp64 from the
+// first add to the last, so the column sums do not depend on how the rows are grouped into blocks, chains or launches (two schedules of the
+// same step give the same dgamma / dbeta up to the final rounding to fp32) and carry no fp32 summation error of their own.
+typedef double fc_ln_part_t;
 struct FcLnBwdP {
   const void* dy; const void* x; const float* mean; const float* rstd; const float* g; const void* res; void* dx; void* dx_scaled;
-  const float* rowscale; float* partial; int rows_per_sample; int M; int blk0; int pad;
+  const float* rowscale; fc_ln_part_t* partial; int rows_per_sample; int M; int blk0; int pad;
 };
 struct FcLnBwdArgs { FcLnBwdP p[2]; int nprob; int D; };
 int fc_layernorm_grouped_ok(int D);
@@ -29,12 +33,12 @@ int fc_layernorm_bwd_grouped(int dt, FcLnBwdArgs a, hipStream_t s);
 // dgamma / dbeta = column sums of the partial rows (of up to two partial sets: two micro-batch chains); accumulate = 0: plain store (the
 // gradient buffer need not be zeroed), 1: added to the existing value.  No atomics: two entries must not name the same dg / db.
 struct FcLnReduce {
-  const float* partial;
-  const float* partial2;
+  const fc_ln_part_t* partial;
+  const fc_ln_part_t* partial2;
   float* dg;
   float* db;
   int nblocks, nblocks2, D, accumulate;
-  const float* partial3;   // a third micro-batch chain's partial rows (three-chain backward)
+  const fc_ln_part_t* partial3;   // a third micro-batch chain's partial rows (three-chain backward)
   int nblocks3, pad_;
 };
 int fc_layernorm_bwd_partial_blocks(int M);
@@ -44,7 +48,7 @@ int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t
 int fc_layernorm_fwd(int dt, const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
                      int M, int D, float eps, hipStream_t s);
 int fc_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
-                     const void* res, void* dx, float* dg, float* db, int M, int D, hipStream_t s, float* partial = nullptr,
+                     const void* res, void* dx, float* dg, float* db, int M, int D, hipStream_t s, fc_ln_part_t* partial = nullptr,
                      void* dx_scaled = nullptr, const float* rowscale = nullptr, int rows_per_sample = 1);
 int fc_rowscale(int dt, const void* src, void* dst, const float* rs, int rows_per_sample, int M, int D, hipStream_t s);
 

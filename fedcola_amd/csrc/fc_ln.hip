@@ -50,6 +50,8 @@ __device__ __forceinline__ float sum16(float v) {   // over the 16 lanes that sh
   return v;
 }
 
+template <typename T> struct LnAcc { typedef float type; };          // in-lane column sums: see k_ln_bwd_g
+template <> struct LnAcc<float> { typedef double type; };
 #define LN_FWD_RG 2                         // row groups (of 4 rows) per wave
 #define LN_FWD_ROWS (16 * LN_FWD_RG)        // rows per block (4 waves)
 
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(256) k_ln_fwd_g(FcLnFwdArgs a) {
 template <typename T, int CH, int LN_BWD_RG>
 __global__ void __launch_bounds__(256) k_ln_bwd_g(FcLnBwdArgs a) {
   constexpr int LN_BWD_ROWS = 16 * LN_BWD_RG;
-  extern __shared__ float red_dyn[];   // [4 waves][2][D]
+  extern __shared__ double red_dyn[];  // [4 waves][2][D]
   const bool second = a.nprob > 1 && (int)blockIdx.x >= a.p[1].blk0;
   const FcLnBwdP& P = second ? a.p[1] : a.p[0];
   const int D = a.D, nc = D >> 3;
@@ -152,12 +154,17 @@ __global__ void __launch_bounds__(256) k_ln_bwd_g(FcLnBwdArgs a) {
       }
     }
   }
-  float gg[CH][8], ag[CH][8], ab[CH][8];
+  // Column sums: fp32 storage (the parity mode) adds in fp64 from the first add; bf16 storage adds the lane's LN_BWD_RG (<= 2) products
+  // in fp32 -- one rounding of 2^-24 per pair, far below the bf16 inputs' own 2^-9 -- and continues in fp64 from there (shuffles, LDS,
+  // partial rows, reduction): fp64 adds per element made this HBM-bound kernel 40 % slower (10.6 -> 15.1 us at 12 608 rows).
+  typedef typename LnAcc<T>::type acc_t;
+  float gg[CH][8];
+  acc_t ag[CH][8], ab[CH][8];
 #pragma unroll
   for (int t = 0; t < CH; ++t) {
     const int c = sub + 16 * t;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { ag[t][i] = 0.f; ab[t][i] = 0.f; gg[t][i] = 0.f; }
+    for (int i = 0; i < 8; ++i) { ag[t][i] = 0; ab[t][i] = 0; gg[t][i] = 0.f; }
     if (c < nc) ld8f(P.g + c * 8, gg[t]);
   }
   const float invD = 1.0f / (float)D;
@@ -174,7 +181,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd_g(FcLnBwdArgs a) {
         const float xh = (xv[i] - mu[q]) * rs[q];
         const float dxh = d[i] * gg[t][i];
         s1 += dxh; s2 += dxh * xh;
-        if (live) { ag[t][i] += d[i] * xh; ab[t][i] += d[i]; }
+        if (live) { ag[t][i] += (acc_t)(d[i] * xh); ab[t][i] += (acc_t)d[i]; }
       }
     }
     const float m1 = sum16(s1) * invD, m2 = sum16(s2) * invD;
@@ -204,26 +211,25 @@ __global__ void __launch_bounds__(256) k_ln_bwd_g(FcLnBwdArgs a) {
   }
   // column sums: the four row slots of the wave (lanes l, l+16, l+32, l+48 hold the same columns), then the four waves through LDS
 #pragma unroll
-  for (int t = 0; t < CH; ++t)
+  for (int t = 0; t < CH; ++t) {
+    const int c = sub + 16 * t;
+    double* r0 = red_dyn + (wave * 2 + 0) * D + c * 8;
+    double* r1 = red_dyn + (wave * 2 + 1) * D + c * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      ag[t][i] += __shfl_xor(ag[t][i], 16, 64); ag[t][i] += __shfl_xor(ag[t][i], 32, 64);
-      ab[t][i] += __shfl_xor(ab[t][i], 16, 64); ab[t][i] += __shfl_xor(ab[t][i], 32, 64);
-    }
-  if (slot == 0) {
-#pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      const int c = sub + 16 * t;
-      if (c < nc) {
-        float* r0 = red_dyn + (wave * 2 + 0) * D + c * 8;
-        float* r1 = red_dyn + (wave * 2 + 1) * D + c * 8;
-        *(float4*)r0 = make_float4(ag[t][0], ag[t][1], ag[t][2], ag[t][3]); *(float4*)(r0 + 4) = make_float4(ag[t][4], ag[t][5], ag[t][6], ag[t][7]);
-        *(float4*)r1 = make_float4(ab[t][0], ab[t][1], ab[t][2], ab[t][3]); *(float4*)(r1 + 4) = make_float4(ab[t][4], ab[t][5], ab[t][6], ab[t][7]);
+    for (int i = 0; i < 8; i += 2) {
+      double a0 = (double)ag[t][i], a1 = (double)ag[t][i + 1], b0 = (double)ab[t][i], b1 = (double)ab[t][i + 1];
+      a0 += __shfl_xor(a0, 16, 64); a0 += __shfl_xor(a0, 32, 64);
+      a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+      b0 += __shfl_xor(b0, 16, 64); b0 += __shfl_xor(b0, 32, 64);
+      b1 += __shfl_xor(b1, 16, 64); b1 += __shfl_xor(b1, 32, 64);
+      if (slot == 0 && c < nc) {
+        *(double2*)(r0 + i) = make_double2(a0, a1);
+        *(double2*)(r1 + i) = make_double2(b0, b1);
       }
     }
   }
   __syncthreads();
-  float* pp = P.partial + (size_t)lblk * 2 * D;
+  fc_ln_part_t* pp = P.partial + (size_t)lblk * 2 * D;
   for (int i = threadIdx.x; i < 2 * D; i += 256) {
     const int h = i >= D, col = i - h * D;
     pp[i] = red_dyn[(0 * 2 + h) * D + col] + red_dyn[(1 * 2 + h) * D + col] + red_dyn[(2 * 2 + h) * D + col] + red_dyn[(3 * 2 + h) * D + col];
@@ -234,12 +240,12 @@ __global__ void __launch_bounds__(256) k_ln_bwd_g(FcLnBwdArgs a) {
 // instance): 16 waves stride the partial rows, combine in LDS, ONE plain store per column (accumulate = 1: an add into the existing
 // value, for callers that keep a running gradient) -- no atomics, fixed order.
 __global__ void __launch_bounds__(1024) k_ln_reduce(const FcLnReduce* __restrict__ tab) {
-  __shared__ float red[16][64];
+  __shared__ double red[16][64];
   const FcLnReduce e = tab[blockIdx.y];
   const int W = 2 * e.D;
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
   if (blockIdx.x * 64 >= W) return;
-  float acc = 0.f;
+  double acc = 0.0;
   if (col < W)
     for (int bk = wave; bk < e.nblocks; bk += 16) acc += e.partial[(size_t)bk * W + col];
   if (e.partial2 && col < W)
@@ -249,11 +255,11 @@ __global__ void __launch_bounds__(1024) k_ln_reduce(const FcLnReduce* __restrict
   red[wave][threadIdx.x & 63] = acc;
   __syncthreads();
   if (wave == 0 && col < W) {
-    float v = 0.f;
+    double v = 0.0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) v += red[w][threadIdx.x];
     float* dst = col < e.D ? e.dg + col : e.db + col - e.D;
-    *dst = e.accumulate ? *dst + v : v;
+    *dst = e.accumulate ? (float)((double)*dst + v) : (float)v;
   }
 }
 int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s) {
@@ -308,7 +314,7 @@ int fc_layernorm_bwd_grouped(int dt, FcLnBwdArgs a, hipStream_t s) {
   }
   if (blocks == 0) return 0;
   const int ch = fc_cdiv(a.D / 8, 16);
-  const size_t lds = sizeof(float) * 8 * a.D;
+  const size_t lds = sizeof(double) * 8 * a.D;
 #define GO(CHN)                                                                                                     \
   do {                                                                                                              \
     if (ln_bwd_rg() == 1) { DISPATCH_DT(dt, hipLaunchKernelGGL((k_ln_bwd_g<T, CHN, 1>), dim3(blocks), dim3(256), lds, s, a)); } \

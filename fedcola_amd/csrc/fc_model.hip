@@ -246,7 +246,7 @@ struct LayerWs {
 struct TowerWs {
   int M = 0, N = 0;
   int dp_off = 0;          // first sample of this (micro-batch) view in the drop-path table
-  size_t ln_stride = 0;    // floats between the partial sets of consecutive LayerNorm instances (sized for the full batch)
+  size_t ln_stride = 0;    // elements between the partial sets of consecutive LayerNorm instances (sized for the full batch)
   void *patches = nullptr, *dtok = nullptr;
   float *emb_mean = nullptr, *emb_rstd = nullptr;
   std::vector<void*> x;
@@ -255,7 +255,7 @@ struct TowerWs {
   float *f, *hmean, *hrstd, *nrm, *out, *logits, *dlogits, *df;
   void *dh, *dO;          // backward temporaries (per tower: the towers run concurrently)
   float *delta;
-  float *ln_partial;      // [2*depth][blocks][2*D] LayerNorm-backward partial sums
+  fc_ln_part_t *ln_partial;   // [2*depth][blocks][2*D] LayerNorm-backward partial sums (fp64)
 };
 struct Ws {
   TowerWs t[2];
@@ -345,7 +345,7 @@ static void carve(const fc_model* m, int B, int n_txt, void* base, Ws& w) {
     t.dO = bp.take((size_t)t.M * D * es);
     t.delta = (float*)bp.take(sizeof(float) * (size_t)B * c.heads * t.N);
     t.ln_stride = ((size_t)fc_layernorm_bwd_partial_blocks(t.M) + 1) * 2 * D;                  // (+1: a slice may round up once more)
-    t.ln_partial = (float*)bp.take(sizeof(float) * (size_t)3 * 2 * c.depth * t.ln_stride);   // x3: micro-batch chains
+    t.ln_partial = (fc_ln_part_t*)bp.take(sizeof(fc_ln_part_t) * (size_t)3 * 2 * c.depth * t.ln_stride);   // x3: micro-batch chains
   }
   w.max_probs = 2 * (4 * c.depth + 1);
   w.probs = (FcTnProblem*)bp.take(sizeof(FcTnProblem) * w.max_probs);
@@ -497,9 +497,9 @@ struct Ctx {
   struct LayerRec* rec = nullptr;              // non-null while a layer is being captured into a graph: host-side notes are recorded too
   // queue the reduction of one LayerNorm backward's partial rows.  Two micro-batch chains of one tower share dg / db: one entry, two
   // partial sets (the reduction uses no atomics).  Host-only: a replayed layer graph repeats its notes (LayerRec).
-  int note_ln(float* partial, float* dg, float* db, int M, int D) const;
+  int note_ln(fc_ln_part_t* partial, float* dg, float* db, int M, int D) const;
   int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* g, const void* res, void* dx, float* dg,
-             float* db, int M, int D, float* partial, void* dx_scaled = nullptr, const float* rowscale = nullptr, int rps = 1) const {
+             float* db, int M, int D, fc_ln_part_t* partial, void* dx_scaled = nullptr, const float* rowscale = nullptr, int rps = 1) const {
     int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, lnq ? partial : nullptr, dx_scaled, rowscale, rps);
     if (r == 1) return note_ln(partial, dg, db, M, D);
     if (r == 0 && rec) mark_ungraphable();     // the atomic fallback wrote dg / db itself: fine eagerly, but keep such layers out of graphs
@@ -563,10 +563,10 @@ struct Ctx {
   }
 };
 
-struct LnNote { float* partial; float* dg; float* db; int M, D; };
+struct LnNote { fc_ln_part_t* partial; float* dg; float* db; int M, D; };
 struct LayerRec { std::vector<LnNote> ln; bool ungraphable = false; };
 void Ctx::mark_ungraphable() const { if (rec) rec->ungraphable = true; }
-int Ctx::note_ln(float* partial, float* dg, float* db, int M, int D) const {
+int Ctx::note_ln(fc_ln_part_t* partial, float* dg, float* db, int M, int D) const {
   if (rec) rec->ln.push_back(LnNote{partial, dg, db, M, D});
   for (FcLnReduce& e : *lnq)
     if (e.dg == dg) {
@@ -671,7 +671,7 @@ static int ln_fwd_multi(const Ctx& c, const LnFwdD* d, int n, int D, float eps) 
 }
 struct LnBwdD {
   const void* dy; const void* x; const float* mean; const float* rstd; const float* g; const void* res; void* dx; float* dg; float* db; int M;
-  float* partial; void* dx_scaled; const float* rowscale; int rps;
+  fc_ln_part_t* partial; void* dx_scaled; const float* rowscale; int rps;
 };
 static int ln_bwd_multi(const Ctx& c, const LnBwdD* d, int n, int D) {
   bool ok = fc_layernorm_grouped_ok(D) && n <= 2 && c.lnq;
@@ -2194,15 +2194,18 @@ extern "C" int fc_k_layernorm_bwd(int32_t dt, const void* dy, const void* x, con
 }
 // the in-model form of the LayerNorm backward: per-block dgamma / dbeta partial rows (room for fc_k_layernorm_partial_floats(M, D)
 // floats) + the grouped reduction, instead of atomics
-extern "C" size_t fc_k_layernorm_partial_floats(int32_t M, int32_t D) { return (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D + 64; }
+extern "C" size_t fc_k_layernorm_partial_floats(int32_t M, int32_t D) {      // (the partial rows are fp64: two floats per element)
+  return 2 * ((size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D) + 64;
+}
 extern "C" int fc_k_layernorm_bwd_partial(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
                                           const void* res, void* dx, float* dg, float* db, int32_t M, int32_t D, float* partial, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, partial);
+  fc_ln_part_t* part = (fc_ln_part_t*)partial;
+  int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, part);
   if (r != 1) return r;
   // one-entry reduction table at the tail of `partial` (the grouped reduction adds into dg / db)
-  FcLnReduce e{partial, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, 1};
-  FcLnReduce* tab = (FcLnReduce*)(partial + (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D);
+  FcLnReduce e{part, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, 1};
+  FcLnReduce* tab = (FcLnReduce*)(part + (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D);
   FC_CHECK_HIP(hipMemcpyAsync(tab, &e, sizeof(e), hipMemcpyHostToDevice, s));
   FC_CHECK_HIP(hipStreamSynchronize(s));      // `e` is a stack temporary (test entry point)
   return fc_ln_reduce_grouped(tab, 1, D, s);

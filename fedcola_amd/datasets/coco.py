@@ -86,6 +86,11 @@ class CocoCaptionsCap(Dataset):
         """coco.py:123-128: keep the LAST num_samples caption ids."""
         self.ids = list(operator.itemgetter(*np.arange(-num_samples, 0))(self.ids))
 
+    def _target(self, caption):
+        if self.tokenizer is not None:
+            return self.tokenizer(caption, padding="max_length", truncation=True, max_length=self.max_length, return_tensors="pt")["input_ids"][0]
+        return caption
+
     def __getitem__(self, index):
         from PIL import Image
         annotation_id = self.ids[index]
@@ -94,11 +99,16 @@ class CocoCaptionsCap(Dataset):
         img = Image.open(os.path.join(self.root, self.coco.imgs[image_id]["file_name"])).convert("RGB")
         if self.transform is not None:
             img = self.transform(img)
-        if self.tokenizer is not None:
-            target = self.tokenizer(caption, padding="max_length", truncation=True, max_length=self.max_length, return_tensors="pt")["input_ids"][0]
-        else:
-            target = caption
-        return img, target, image_id, annotation_id, index
+        return img, self._target(caption), image_id, annotation_id, index
+
+    # ---- what loaders.cache.DecodedCache asks of a caption dataset (see datasets/flickr30k.py)
+    def image_key(self, index):
+        return self.coco.anns[self.ids[index]]["image_id"]
+
+    def sample_without_image(self, index):
+        annotation_id = self.ids[index]
+        annotation = self.coco.anns[annotation_id]
+        return None, self._target(annotation["caption"]), annotation["image_id"], annotation_id, index
 
     def __len__(self):
         return len(self.ids)

@@ -24,16 +24,27 @@ class Flickr30kCap(Dataset):
         self.n_images = len(set(self.images))
         self.iid_to_cls = {}
 
-    def __getitem__(self, index):
-        from PIL import Image
-        image = Image.open(os.path.join(self.root, "flickr30k_images", self.images[index])).convert("RGB")
+    def _caption(self, index):
         caption = self.captions[index]
-        if self.transform is not None:
-            image = self.transform(image)
         if self.tokenizer is not None:
             caption = self.tokenizer(caption, padding="max_length", truncation=True, max_length=self.max_length,
                                      return_tensors="pt")["input_ids"][0]
-        return image, caption, index // 5, index, index
+        return caption
+
+    def __getitem__(self, index):
+        from PIL import Image
+        image = Image.open(os.path.join(self.root, "flickr30k_images", self.images[index])).convert("RGB")
+        if self.transform is not None:
+            image = self.transform(image)
+        return image, self._caption(index), index // 5, index, index
+
+    # ---- what loaders.cache.DecodedCache asks of a caption dataset: which image a sample shows (five captions share one), and the
+    # sample's other fields without decoding the image
+    def image_key(self, index):
+        return self.images[index]
+
+    def sample_without_image(self, index):
+        return None, self._caption(index), index // 5, index, index
 
     def __len__(self):
         return len(self.images)

@@ -33,12 +33,18 @@ def _worker_init():
 
 
 class PinnedBatchLoader:
-    def __init__(self, dataset, batch_size: int, shuffle: bool = False, drop_last: bool = False, workers: int = 4, pin: bool = True, ahead: int = 2):
+    def __init__(self, dataset, batch_size: int, shuffle: bool = False, drop_last: bool = False, workers: int = 4, pin: bool = True, ahead: int = 2,
+                 raw: bool = False):
+        """raw: batches come from ``dataset.get_batch_raw`` (a DecodedCache's uint8 image codes: a quarter of the bytes, no host
+        arithmetic) and must pass through ``loader.device_finish`` after their copy to the device -- DevicePrefetcher does that on its
+        copy stream.  Only for consumers that do (FedavgClient's training loop)."""
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
         self.workers, self.pin, self.ahead = max(1, int(workers)), pin and torch.cuda.is_available(), max(0, int(ahead))
         self._spec = None
         self._pool = None
-        gb = getattr(dataset, "get_batch", None)
+        self.raw = bool(raw) and hasattr(dataset, "get_batch_raw") and hasattr(dataset, "expand_on_device")
+        gb = getattr(dataset, "get_batch_raw" if self.raw else "get_batch", None)
+        self._fetch = gb
         self._into = False
         if gb is not None:
             import inspect
@@ -58,7 +64,19 @@ class PinnedBatchLoader:
     def __getstate__(self):              # copies / pickles of a loader (deep-copied clients) start without the pool
         d = dict(self.__dict__)
         d["_pool"] = None
+        d["_fetch"] = None
         return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._fetch = getattr(self.dataset, "get_batch_raw" if self.raw else "get_batch", None)
+
+    def device_finish(self, tensors):
+        """After the copy to the device (on the copy's stream): raw image codes -> the dataset's float images.  Identity otherwise."""
+        if self.raw and tensors and torch.is_tensor(tensors[0]) and tensors[0].dtype == torch.uint8:
+            tensors = list(tensors)
+            tensors[0] = self.dataset.expand_on_device(tensors[0])
+        return tensors
 
     def __del__(self):
         pool = getattr(self, "_pool", None)
@@ -109,16 +127,16 @@ class _BatchIter:
         chunks = [(c * k, idxs[c * k: (c + 1) * k]) for c in range(W) if c * k < n]
         if hasattr(ld.dataset, "get_batch"):          # vectorised fetch (in-memory / pre-decoded datasets): one gather per field and chunk
             if ld._spec is None:                       # field shapes / dtypes: asked once per loader, not once per batch
-                ld._spec = [(tuple(t.shape[1:]), t.dtype) for t in map(torch.as_tensor, ld.dataset.get_batch(idxs[:1]))]
+                ld._spec = [(tuple(t.shape[1:]), t.dtype) for t in map(torch.as_tensor, ld._fetch(idxs[:1]))]
             bufs = [torch.empty((n,) + sh, dtype=dt, pin_memory=ld.pin) for sh, dt in ld._spec]
 
             def job(ch):
                 j0, ii = ch
                 views = [buf[j0: j0 + len(ii)] for buf in bufs]
                 if ld._into:                           # get_batch(indices, out=views): gathered straight into the pinned batch (one copy)
-                    ld.dataset.get_batch(ii, out=views)
+                    ld._fetch(ii, out=views)
                 else:
-                    for v, t in zip(views, ld.dataset.get_batch(ii)):
+                    for v, t in zip(views, ld._fetch(ii)):
                         v.copy_(torch.as_tensor(t))
             list(pool.map(job, chunks))
             return tuple(bufs)

@@ -53,6 +53,9 @@ class DevicePrefetcher:
                     self._pinned[key] = buf
                 buf.copy_(t)                                          # pageable -> pinned (the only host-side copy)
                 out.append(buf.to(self.device, non_blocking=True))    # pinned -> HBM on the copy stream
+            finish = getattr(self.loader, "device_finish", None)      # a raw loader's uint8 image codes -> floats, behind the copy
+            if finish is not None:
+                out = list(finish(out))
             ev = torch.cuda.Event()
             ev.record(stream)
         return out, ev

@@ -219,6 +219,12 @@ int fc_scale_segments(float* buf, const int64_t* seg_offset, const int64_t* seg_
 /* FedavgClient.upload aux fold (fedavgclient.py:173-181): dst[weight] = W + A*s for every re-param linear, rest copied */
 int fc_upload_fold(const fc_model_t* m, const float* params, float* dst, void* stream);
 
+/* ---- input side: a batch of pre-decoded images kept as uint8 codes [n_images, C, HW] with the per-channel
+ * table lut[C][256] = Normalize(ToTensor(u)) of the reference's transform chain (src/loaders/data.py:106-109; built by
+ * fedcola_amd/loaders/cache.py, which verifies that the codes reproduce the dataset's own float tensors bit for bit) -> float32
+ * [n_images, C, HW] on the device: dst = lut[c][src].  C <= 4. */
+int fc_image_u8_to_f32(const uint8_t* src, const float* lut, float* dst, int64_t n_images, int32_t C, int32_t HW, void* stream);
+
 /* ---- retrieval evaluation: COCOEvaluator.evaluate_recall (src/metrics/eval_coco.py:296-351,
  * ParallelMatMulModule :48-69) on device.  q [nq,d], g [ng,d]: float64 row-major features (the reference holds the extracted
  * features as float64, eval_coco.py:155-156, and multiplies them with Tensor.mm, :55); labels: int64 class ids

@@ -262,3 +262,71 @@ def test_bert_vocab_tokenizer_against_live_hf_tokenizer():
         for L in (32, 40):
             assert mine(s, padding="max_length", truncation=True, max_length=L, return_tensors="pt")["input_ids"][0].tolist() == \
                 hf(s, padding="max_length", truncation=True, max_length=L, return_tensors="pt")["input_ids"][0].tolist(), s
+
+
+def _imnorm(size):
+    """The reference's --resize N --imnorm chain (Resize, ToTensor, Normalize(0.5, 0.5); src/loaders/data.py:90-109) without
+    torchvision: PIL resize + the tensor ops of torchvision's to_tensor / normalize."""
+    def t(im):
+        im = im.resize((size, size))
+        x = torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float().div(255)
+        return x.sub_(0.5).div_(0.5)
+    return t
+
+
+def test_decoded_cache_serves_the_datasets_own_samples_bit_for_bit(tmp_path):
+    """loaders.cache.DecodedCache over Flickr30kCap (also behind a Subset + the reference's SubsetWrapper): every sample and every batch
+    equals the dataset's own, bit for bit; the store is uint8 (lossless by verification) and holds one image per five captions; the
+    client's loader over it yields the DataLoader's batches in the DataLoader's order under the same RNG state."""
+    from fedcola_amd.datasets.flickr30k import Flickr30kCap
+    from fedcola_amd.loaders import DecodedCache, PinnedBatchLoader
+    root = str(tmp_path)
+    _make_flickr(root, n_images=7)
+    ds = Flickr30kCap(root, split="train", transform=_imnorm(12), tokenizer=_tok, max_length=8)
+    assert DecodedCache.applicable(ds)
+    dc = DecodedCache(ds).build()
+    assert dc.lut is not None and dc.u8.shape == (7, 3, 12, 12) and len(dc) == 35
+    for i in (0, 4, 5, 17, 34):
+        a, b = ds[i], dc[i]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2:] == b[2:]
+    got = dc.get_batch([3, 33, 10])
+    for j, i in enumerate([3, 33, 10]):
+        assert torch.equal(got[0][j], ds[i][0]) and torch.equal(got[1][j], ds[i][1]) and [int(g[j]) for g in got[2:]] == list(ds[i][2:])
+
+    class SubsetWrapper(torch.utils.data.Dataset):          # src/loaders/data.py:35-49
+        def __init__(self, subset):
+            self.subset = subset
+        def __getitem__(self, i):
+            return self.subset[i]
+        def __len__(self):
+            return len(self.subset)
+    sub = SubsetWrapper(torch.utils.data.Subset(ds, [30, 31, 32, 33, 34, 5, 6, 7, 8, 9, 20, 21]))
+    assert DecodedCache.applicable(sub)
+    sc = DecodedCache(sub)
+    torch.manual_seed(11)
+    ref = list(torch.utils.data.DataLoader(sub, batch_size=5, shuffle=True))
+    torch.manual_seed(11)
+    mine = list(PinnedBatchLoader(sc, 5, shuffle=True, workers=3, pin=False))
+    assert sc.built and sc.u8.shape[0] == 3                 # three images behind the twelve caption samples
+    assert len(ref) == len(mine) == 3
+    for r, m in zip(ref, mine):
+        assert len(r) == len(m)
+        for x, y in zip(r, m):
+            assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
+
+
+def test_decoded_cache_refuses_random_transforms_and_keeps_floats_when_uint8_would_lose_bits(tmp_path):
+    from fedcola_amd.datasets.flickr30k import Flickr30kCap
+    from fedcola_amd.loaders import DecodedCache
+    root = str(tmp_path)
+    _make_flickr(root, n_images=3)
+    base = _imnorm(8)
+    rnd = Flickr30kCap(root, split="train", transform=lambda im: base(im) + torch.rand(()) * 1e-3, tokenizer=_tok, max_length=8)
+    assert not DecodedCache.applicable(rnd)                 # a random transform: the client keeps the reference's DataLoader
+    odd = Flickr30kCap(root, split="train", transform=lambda im: base(im) * 1.0001, tokenizer=_tok, max_length=8)
+    dc = DecodedCache(odd).build()
+    assert dc.lut is None and dc.f32.shape == (3, 3, 8, 8)  # not a ToTensor / Normalize table: the floats themselves are kept
+    assert torch.equal(dc[7][0], odd[7][0]) and torch.equal(dc.get_batch([7, 1])[0][0], odd[7][0])
+    with pytest.raises(ValueError):
+        DecodedCache(odd, store="uint8").build()
+    assert not DecodedCache.applicable(torch.utils.data.TensorDataset(torch.zeros(4, 3, 8, 8)))     # no image_key: not a caption dataset

@@ -139,6 +139,62 @@ def _layer_local(model, sd, grads, B, seq, tower, N, l, D, H, masks=None, aux_tr
     return worst
 
 
+def _embed_local(model, sd, grads, img, ids, B, seq, tower, N, D, patch=16):
+    """The embedding layer, teacher-forced like the blocks: forward -- the oracle's embedding (emulating bf16) of the RAW batch against
+    the workspace's x_0 (and the patch matrix); backward -- the oracle's embedding backward of the library's own gx_0 against the
+    library's embeddings.* gradients (and dtok).  Returns the worst (name, rel L2)."""
+    worst = ("", 0.0)
+
+    def chk(what, got, exp, t=TOL):
+        nonlocal worst
+        r = _rel_l2(got, exp)
+        if r > worst[1]:
+            worst = (f"tower {tower} embedding {what}", r)
+        assert r <= t, f"tower {tower} embedding {what}: relative L2 {r:.3e}"
+
+    gx0 = _ws_tensor(model, B, seq, tower, 0, "gx", (B, N, D))
+    x0 = _ws_tensor(model, B, seq, tower, 0, "x", (B, N, D))
+    if tower == 0:
+        e = "embeddings.0"
+        kp = 3 * patch * patch
+        with O.emulate_bf16():
+            pt = O.R(O.patchify(img, patch))
+            Wp = O.R(sd[e + ".embed.proj.weight"].reshape(D, -1))
+            tok = O.linear_fwd(pt, Wp, sd[e + ".embed.proj.bias"])
+            h = O.R(torch.cat([sd[e + ".cls_token"].expand(B, -1, -1), tok], 1) + sd[e + ".pos_embed"])
+        chk("patches", _ws_tensor(model, B, seq, 0, 0, "patches", (B, N - 1, kp)), pt, 1e-6)       # a pure re-arrangement + one rounding
+        chk("x_0", x0, h)
+        dtok = gx0[:, 1:]
+        chk("dtok", _ws_tensor(model, B, seq, 0, 0, "dtok", (B, N - 1, D)), dtok, 1e-6)
+        _, dWp, dbp = O.linear_bwd(dtok, pt, Wp)
+        chk("grad embed.proj.weight", grads[e + ".embed.proj.weight"], dWp.reshape(grads[e + ".embed.proj.weight"].shape))
+        # column sums over the batch of bf16 rows (fp32 atomics in the library, any order): against the exact sums of the same rows
+        chk("grad embed.proj.bias", grads[e + ".embed.proj.bias"], dbp, 1e-3)
+        chk("grad pos_embed", grads[e + ".pos_embed"], gx0.sum(0, keepdim=True), 1e-3)
+        chk("grad cls_token", grads[e + ".cls_token"], gx0[:, 0].sum(0).reshape(1, 1, D), 1e-3)
+    else:
+        pre = f"embeddings.{tower}.text_embeddings"
+        emb = sd[pre + ".word_embeddings.weight"][ids] + sd[pre + ".token_type_embeddings.weight"][0] + sd[pre + ".position_embeddings.weight"][:seq]
+        hh, saved = O.ln_fwd(emb, sd[pre + ".LayerNorm.weight"], sd[pre + ".LayerNorm.bias"], O.LN_EPS_BERT)
+        with O.emulate_bf16():
+            h = O.R(hh)
+        chk("x_0", x0, h)
+        de, dg, db = O.ln_bwd(gx0, sd[pre + ".LayerNorm.weight"], saved)
+        dword = torch.zeros_like(sd[pre + ".word_embeddings.weight"])
+        dword.index_add_(0, ids.reshape(-1), de.reshape(-1, D))
+        dword[0] = 0
+        chk("grad word_embeddings", grads[pre + ".word_embeddings.weight"], dword, 1e-3)
+        dpos = torch.zeros_like(sd[pre + ".position_embeddings.weight"])
+        dpos[:seq] = de.sum(0)
+        chk("grad position_embeddings", grads[pre + ".position_embeddings.weight"], dpos, 1e-3)
+        dty = torch.zeros_like(sd[pre + ".token_type_embeddings.weight"])
+        dty[0] = de.reshape(-1, D).sum(0)
+        chk("grad token_type_embeddings", grads[pre + ".token_type_embeddings.weight"], dty, 1e-3)
+        chk("grad LayerNorm.weight", grads[pre + ".LayerNorm.weight"], dg, 1e-3)
+        chk("grad LayerNorm.bias", grads[pre + ".LayerNorm.bias"], db, 1e-3)
+    return worst
+
+
 def _default_init(mk, seed, scale=None):
     """The reference's default initialisation (mome.py:708-769) under torch.manual_seed, with non-zero pos / cls (zeros by default)
     and, for re-param linears, a non-zero cross_modal_scale so that those terms are exercised."""
@@ -221,6 +277,9 @@ def test_vit_s_b64_bf16_layer_by_layer(wseed, bseed):
             w = _layer_local(model, sd, grads, B, seq, tower, N, l, D, H)
             if w[1] > worst[1]:
                 worst = w
+        w = _embed_local(model, sd, grads, img, ids, B, seq, tower, N, D)        # the layer below block 0: raw batch -> x_0, gx_0 -> embeddings.* gradients
+        if w[1] > worst[1]:
+            worst = w
     # heads + loss from the library's own last-layer rows
     outs = []
     for tower, N in ((0, 197), (1, seq)):
@@ -255,6 +314,8 @@ def test_vit_tiny_img_client_bf16_layer_by_layer():
         w = _layer_local(model, sd, grads, B, 0, 0, 197, l, D, H)
         if w[1] > worst[1]:
             worst = w
+    w = _embed_local(model, sd, grads, img, ids, B, 0, 0, 197, D)
+    worst = max(worst, w, key=lambda t: t[1])
     print("ViT-Tiny layer-by-layer worst:", worst)
 
 
@@ -280,6 +341,8 @@ def test_other_image_size_and_odd_batch_bf16_layer_by_layer():
             w = _layer_local(model, sd, grads, B, seq, tower, N, l, D, H)
             if w[1] > worst[1]:
                 worst = w
+        w = _embed_local(model, sd, grads, img, ids, B, seq, tower, N, D)
+        worst = max(worst, w, key=lambda t: t[1])
     print("160-pixel / B = 27 layer-by-layer worst:", worst)
 
 

@@ -366,3 +366,56 @@ def test_prox_term_kernel_vs_oracle():
         else:
             assert (got - 2 * gr[k]).abs().max() <= 1e-5 * max(1e-3, float(gr[k].abs().max())), k
     _lib.check(L.fc_model_set_trainable(m._handle.h, m.segments[frozen]["index"], 1))
+
+
+def test_image_u8_expansion_kernel_is_the_table_lookup():
+    """fc_image_u8_to_f32 (the device half of loaders.cache.DecodedCache): dst = lut[c][src], vector form (HW % 16 == 0) and scalar form."""
+    import ctypes as C
+    from fedcola_amd import _lib
+    from fedcola_amd.loaders.cache import _lut
+    lut = _lut(((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)))
+    g = torch.Generator().manual_seed(3)
+    for n, H, W in ((5, 224, 224), (3, 7, 9)):
+        u = torch.randint(0, 256, (n, 3, H, W), generator=g, dtype=torch.uint8)
+        exp = torch.stack([lut[c][u[:, c].long()] for c in range(3)], 1)
+        ud, ld = u.cuda(), lut.cuda().contiguous()
+        out = torch.empty(n, 3, H, W, device="cuda")
+        _lib.check(_lib.lib().fc_image_u8_to_f32(_lib.ptr(ud), _lib.ptr(ld), _lib.ptr(out), n, 3, H * W, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), exp)
+
+
+def test_client_round_over_a_caption_dataset_on_disk_uses_the_decoded_cache_and_changes_nothing(tmp_path):
+    """A FedavgClient over Flickr30kCap (files on disk, the reference's --resize 224 --imnorm chain): the default device loader is the
+    pre-decoded cache (uint8 codes over PCIe, expanded on the copy stream) -- same batches in the same order as the reference's DataLoader,
+    so the same result dict and the same weights as with args.decode_cache = False (up to the atomics of the embedding gradients)."""
+    import numpy as np
+    from test_data_golden import _make_flickr, _tok, _imnorm
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    from fedcola_amd.datasets.flickr30k import Flickr30kCap
+    from fedcola_amd.loaders import DecodedCache, PinnedBatchLoader
+    root = str(tmp_path)
+    _make_flickr(root, n_images=5)
+    ds = Flickr30kCap(root, split="train", transform=_imnorm(224), tokenizer=_tok, max_length=8)
+    out = {}
+    for cache in (True, False):
+        args = RefArgs(E=2, B=6, lr=1e-3, optimizer="AdamW", no_shuffle=False, max_grad_norm=0.0)
+        args.decode_cache = cache
+        torch.manual_seed(7)
+        cl = FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
+        if cache:
+            assert isinstance(cl.train_loader, PinnedBatchLoader) and cl.train_loader.raw and isinstance(cl.train_loader.dataset, DecodedCache)
+            assert isinstance(cl.test_loader, PinnedBatchLoader) and not cl.test_loader.raw          # evaluation reads floats
+        else:
+            assert isinstance(cl.train_loader, torch.utils.data.DataLoader)
+        cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cuda"
+        cl.download({"Flickr30k": toy_model()})
+        torch.manual_seed(99)                                # the shuffles of both runs draw from the same RNG state
+        res = cl.update()
+        out[cache] = (res, {k: v.cpu() for k, v in cl.upload().items()})
+        if cache:
+            assert cl.train_loader.dataset.built and cl.train_loader.dataset.lut is not None and cl.train_loader.dataset.u8.shape[0] == 5
+    for e in (1, 2):
+        assert abs(out[True][0][e]["loss"] - out[False][0][e]["loss"]) <= 1e-5 * max(1.0, abs(out[False][0][e]["loss"]))
+    for k, v in out[False][1].items():
+        assert float((out[True][1][k] - v).abs().max()) <= 2.5e-3, k      # (sign flips of near-zero Adam steps: see the test above)

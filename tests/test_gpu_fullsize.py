@@ -115,8 +115,30 @@ def test_vit_b_width_step_vs_oracle(kind, prec, otol, gtol):
             worst1d = max(worst1d, (k, rel), key=lambda t: t[1])
     print(f"{kind} {prec}: worst gradient tensor {worst}, worst 1-D {worst1d}")
     assert worst[1] <= gtol, f"worst gradient tensor {worst}"
-    # bias / LayerNorm vectors at B = 8 are column sums over a few hundred rows (320 text rows) that cancel to ~1e-3 of their
-    # summands: two fp32 summation orders (this library's, torch's on the CPU) differ by up to ~1e-4 of the result's maximum (measured 9.9e-5
-    # on a text qkv.bias, and 1.27e-4 after a change that only moved an FMA contraction elsewhere).  fp32: 2e-4 for these vectors, 1e-4
-    # stays for every matrix (weights, embedding tables), the loss and the outputs; bf16: the caller's bound.
-    assert worst1d[1] <= (2e-4 if prec == "fp32" else gtol), f"worst 1-D gradient tensor {worst1d}"
+    # Bias / LayerNorm vectors at B = 8 are column sums over a few hundred rows (320 text rows) that cancel to ~1e-3 of their summands.
+    # The library forms these sums in fp64 (k_colsum_f64, fp64 LayerNorm partial rows), so the summation adds nothing -- but the SUMMANDS
+    # of two fp32 implementations differ by ~1e-6 each, which after the cancellation is ~1e-4 of the result's maximum: that is the
+    # conditioning of the quantity, not an error of either side.  So the vectors are held to 1e-4 against the EXACT gradient (the same
+    # oracle run in fp64), and the fp32 oracle's own distance from it is printed beside ours; against the fp32 oracle the bound is the sum
+    # of the two (2e-4).
+    p64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    b64 = ("img+txt", img.double(), ids) if kind == "img+txt" else ("img", img.double(), y)
+    _, _, grads_64 = O.client_step(p64, cfg, b64, dict(step=0, m={}, v={}), lr=1e-4)
+    ours, theirs = ("", 0.0), ("", 0.0)
+    for k, g64 in grads_64.items():
+        if g64.dim() > 1 or "cross_modal_scale" in k or "embeddings" in k and g64.dim() > 1:
+            continue
+        gk, go = grads[k].double(), grads_o[k].double()
+        if k.endswith("attn.qkv.bias"):
+            D3 = g64.numel() // 3
+            sel = torch.cat([torch.arange(0, D3), torch.arange(2 * D3, 3 * D3)])
+            gk, go, g64 = gk[sel], go[sel], g64[sel]
+        scale = max(float(g64.abs().max()), 1e-7)
+        ours = max(ours, (k, float((gk - g64).abs().max()) / scale), key=lambda t: t[1])
+        theirs = max(theirs, (k, float((go - g64).abs().max()) / scale), key=lambda t: t[1])
+    print(f"{kind} {prec}: 1-D gradients against the fp64 oracle: library {ours}, fp32 oracle {theirs}")
+    if prec == "fp32":
+        assert ours[1] <= 1e-4, f"worst 1-D gradient tensor against the exact gradient {ours}"
+        assert worst1d[1] <= 2e-4, f"worst 1-D gradient tensor against the fp32 oracle {worst1d}"
+    else:
+        assert worst1d[1] <= gtol, f"worst 1-D gradient tensor {worst1d}"

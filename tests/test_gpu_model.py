@@ -143,14 +143,23 @@ def test_microbatch_chains_do_not_change_the_result(tmp_path, kind, B):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "mb_check.py"), str(B), f, kind], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         out[mb] = torch.load(f)
+    worst = {"matrix": ("", 0.0), "vector": ("", 0.0), "atomic": ("", 0.0)}
     for k in out["1"]:
         scale = max(float(out["1"][k].abs().max()), 1e-9)
-        err = float((out["1"][k] - out["2"][k]).abs().max())
-        # weight matrices come from full-batch weight-gradient problems in either schedule; vectors (bias / LayerNorm: column sums whose
-        # partial rows are grouped per chain) and embedding tables (atomic adds) differ by their fp32 summation order, which for a
-        # cancelling sum reaches a few 1e-5 of the maximum (one run in eight crossed 2e-5)
-        tol = 2e-5 if (out["1"][k].dim() > 1 and "embeddings" not in k) else 2e-4
-        assert err <= tol * scale, (k, err / scale)
+        err = float((out["1"][k] - out["2"][k]).abs().max()) / scale
+        # Every row-wise tensor of the step is the same bits in both schedules; what differs is the grouping of rows in the column sums.
+        # matrix: weight gradients, full-batch weight-gradient problems in either schedule.  vector: the linears' biases (column sums
+        # inside those problems) and the blocks' LayerNorm weight / bias (fp64 partial rows: independent of the grouping up to the final
+        # rounding).  atomic: embedding tables, position / type rows, the shared final norm and a classification head -- summed with fp32
+        # atomics whose order is not fixed: equal up to the order of the sum (a cancelling sum reaches a few 1e-5 of its maximum).
+        cls = "atomic" if ("embeddings" in k or k.startswith(("norm.", "heads."))) else ("matrix" if out["1"][k].dim() > 1 else "vector")
+        worst[cls] = max(worst[cls], (k, err), key=lambda t: t[1])
+    print(f"schedule invariance {kind} B={B}: {worst}")
+    # measured (round 4, six cases): matrix 0 (the same bits), vector <= 3.3e-6 (cross_modal_scale: an atomically summed scalar product;
+    # LayerNorm weight / bias <= 1e-7), atomic <= 4.2e-7
+    assert worst["matrix"][1] <= 1e-7, worst["matrix"]
+    assert worst["vector"][1] <= 2e-5, worst["vector"]
+    assert worst["atomic"][1] <= 2e-5, worst["atomic"]
 
 
 @pytest.mark.parametrize("kind,width,dw_wide,B", [("img+txt", 128, "2", 0), ("img", 128, "2", 0), ("img+txt", 384, "2", 0), ("img+txt", 384, "1", 0),

@@ -54,6 +54,9 @@ K["proj dX (plain)"] = lambda i: ck(L.fc_k_gemm_epi(1, R(X, i), R(Wp, i), R(Y, i
 K["attn bwd"] = lambda i: ck(L.fc_k_attention_bwd(1, 1, R(QKV, i), R(X, i), R(Y, i), P(lse), P(delta), R(DQKV, i), B, N_tok, H, 64, 0.125, sp))
 K["qkv dX (plain)"] = lambda i: ck(L.fc_k_gemm_epi(1, R(QKV, i), R(Wqkv, i), R(Y, i), M, D, 3 * D, None, None, None, None, sp))
 only = os.environ.get("COLD_ONLY")
+flops = {"qkv fwd (bias)": 2 * M * 3 * D * D, "proj fwd (bias+res)": 2 * M * D * D, "fc1 fwd (gelu, 2 stores)": 2 * M * Hd * D,
+         "fc2 fwd (bias+res)": 2 * M * Hd * D, "fc2 dX (x gelu')": 2 * M * Hd * D, "fc1 dX (plain)": 2 * M * Hd * D,
+         "proj dX (plain)": 2 * M * D * D, "qkv dX (plain)": 2 * M * 3 * D * D,
          "attn fwd": 4 * B * H * N_tok * N_tok * 64, "attn bwd": 10 * B * H * N_tok * N_tok * 64}
 print(f"# rows {M} ({B} x {N_tok}), {reps} launches per kernel, each on another buffer set (ring footprint ~{GB} GB per tensor group of 8); HIP-event time per launch")
 for name, fn in K.items():
