@@ -32,7 +32,7 @@ PAIR_GFLOP = 31.61           # algorithmic GEMM FLOPs per img-txt pair fwd+bwd, 
 STEP_ALG_GB = 10.8           # algorithmic HBM bytes per B=64 step, fully fused bf16
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
 
 
 class Args:
@@ -73,26 +73,40 @@ def roof_shape(B=64):
 ROOF_KIND, ROOF_M, ROOF_N, ROOF_K = roof_shape()
 
 
+def _ring(shape, gb, dtype=None):
+    """Distinct device buffers of `shape` (bf16) whose total footprint is >= gb GB: launches that walk the ring never find their
+    operands in the 256-MB Infinity Cache or in an L2 (the cold protocol of tools/cold_bench.py; VERDICT r03 task 2)."""
+    import torch
+    n = 1
+    for d in shape:
+        n *= d
+    k = max(2, int(gb * 1e9 / (2 * n)) + 1)
+    return [torch.randn(*shape, device="cuda").bfloat16() for _ in range(k)]
+
+
 def gemm_roofline(steps=200):
     """Timed live with HIP events on the stream the kernel is launched on; launches are issued back to back from C (fc_k_gemm),
-    `steps` of them, so that the ~4 us host cost per launch is hidden behind the previous kernels."""
+    `steps` of them, so that the ~4 us host cost per launch is hidden behind the previous kernels.  Cold protocol: every launch
+    reads another A (ring of >= 1 GB), another W (12 matrices: one per layer) and writes another C, as in the model, where the dY operand
+    was written by the previous kernel of the chain and never by this one's previous launch."""
     import torch
     from fedcola_amd import _lib
     L = _lib.lib()
     M, N, K = ROOF_M, ROOF_N, ROOF_K
-    A = torch.randn(M, K, device="cuda").bfloat16()
-    W = torch.randn(K, N, device="cuda").bfloat16()
-    Cm = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    As = _ring((M, K), 1.0)
+    Ws = [torch.randn(K, N, device="cuda").bfloat16() for _ in range(12)]
+    Cs = [torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(len(As))]
     st = torch.cuda.Stream()
     sp = C.c_void_p(st.cuda_stream)
     P = _lib.ptr
+    torch.cuda.synchronize()
     with torch.cuda.stream(st):
-        for _ in range(10):
-            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(A), P(W), P(Cm), M, N, K, None, 0, sp))
+        for i in range(10):
+            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(As[i % len(As)]), P(Ws[i % 12]), P(Cs[i % len(As)]), M, N, K, None, 0, sp))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
-        for _ in range(steps):
-            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(A), P(W), P(Cm), M, N, K, None, 0, sp))
+        for i in range(steps):
+            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(As[i % len(As)]), P(Ws[i % 12]), P(Cs[i % len(As)]), M, N, K, None, 0, sp))
         e1.record(st)
     e1.synchronize()
     ms = e0.elapsed_time(e1) / steps
@@ -106,25 +120,27 @@ def gemm_roofline(steps=200):
         if rec.get("source_stamp") == kernel_source_stamp() and rec.get("shape") == [ROOF_KIND, M, N, K]:
             traffic = rec.get("hbm_bytes_per_launch")
         else:
-            note = "profiles/r03/roofline_pmc.json was measured on other kernel sources / another shape: traffic withheld (re-run tools/collect_profiles.sh)"
+            note = "profiles/r04/roofline_pmc.json was measured on other kernel sources / another shape: traffic withheld (re-run tools/collect_profiles.sh)"
     out = dict(bound="mfma", kernel=f"k_gemm_mfma<KC,KR,bf16,PLAIN> (NN dX GEMM: dh2 = gdu.W1 of the largest backward image chain) {M}x{N}x{K} bf16",
                achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
                traffic=traffic, us_per_launch=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
-               algorithmic_bytes_per_launch=alg_bytes, hbm_frac=round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+               algorithmic_bytes_per_launch=alg_bytes, hbm_frac=round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+               protocol="cold: every launch on another operand / output set out of a >= 1-GB ring (12 weight matrices)")
     if note:
         out["traffic_note"] = note
     # the same kernel over the whole batch's rows (how the one-chain schedule launches it): a third of the batch fills 102 tiles on 256
     # CUs, so the in-model figure above is the tile count's, not the main loop's
     Mf = 64 * 197
-    Af = torch.randn(Mf, K, device="cuda").bfloat16()
-    Cf = torch.empty(Mf, N, device="cuda", dtype=torch.bfloat16)
+    del As, Cs
+    Afs = _ring((Mf, K), 1.0)
+    Cfs = [torch.empty(Mf, N, device="cuda", dtype=torch.bfloat16) for _ in range(len(Afs))]
     with torch.cuda.stream(st):
-        for _ in range(10):
-            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(Af), P(W), P(Cf), Mf, N, K, None, 0, sp))
+        for i in range(10):
+            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(Afs[i % len(Afs)]), P(Ws[i % 12]), P(Cfs[i % len(Afs)]), Mf, N, K, None, 0, sp))
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         f0.record(st)
-        for _ in range(steps):
-            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(Af), P(W), P(Cf), Mf, N, K, None, 0, sp))
+        for i in range(steps):
+            _lib.check(L.fc_k_gemm(1, ROOF_KIND, 1, 1, P(Afs[i % len(Afs)]), P(Ws[i % 12]), P(Cfs[i % len(Afs)]), Mf, N, K, None, 0, sp))
         f1.record(st)
     f1.synchronize()
     msf = f0.elapsed_time(f1) / steps
@@ -367,6 +383,9 @@ def main():
     ap.add_argument("--agg", default="cabi", choices=["torch", "cabi"], help="cross-rank sum of the timed aggregation: the C ABI's own RCCL "
                     "communicator (fc_comm_* / fc_aggregate, default) or torch.distributed.all_reduce (RCCL); the other one runs once after "
                     "the timed region as the cross-check (agg_paths_agree)")
+    ap.add_argument("--clients-per-rank", type=int, default=1, help="N > 1 only: sampled clients per GPU (the reference queues clients when it "
+                    "samples more than it has devices, fedavgserver.py:310-311): each rank trains its clients one after the other and "
+                    "pre-accumulates them locally in ONE blend before the all-reduce")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the h2d_inclusive / client_round / sustained legs (N = 1)")
     ap.add_argument("--h2d", action="store_true", help="non-default: batches start in pinned host memory and reach the GPU through "
                     "fedcola_amd.loaders.DevicePrefetcher (PCIe-inclusive rate; never the headline value)")
@@ -464,7 +483,8 @@ def main():
     plan = comm = None
     if world > 1:
         from fedcola_amd import aggregate as agg
-        cids = list(range(world))                                          # one client per rank
+        cpr = max(1, a.clients_per_rank)
+        cids = list(range(world * cpr))                                    # sampled clients; position p trains on rank p % world (fedavgserver.py:310-311)
         keys = list(model.required_params().keys())
         sizes = {i: 1280 for i in cids}                                    # equal client sizes, scope 'dataset'
         coef = {k: {i: sizes[i] / sum(sizes.values()) for i in cids} for k in keys}
@@ -489,39 +509,67 @@ def main():
         comm = comm_c if a.agg == "cabi" else None
 
     agg_state = {}
+    cpr = max(1, a.clients_per_rank) if world > 1 else 1
+    local_cids = [rank + world * j for j in range(cpr)] if world > 1 else [0]
+    # more clients than ranks: every local client has its own weights; the one model object (handle, workspace, optimizer buffers) trains
+    # them one after the other, as FedavgServer's per-device queue does
+    client_flats = {c: model.flat.data.clone() for c in local_cids} if cpr > 1 else None
+    client_batches = {c: make_batch(B, seq, args.vocab_size, c, dev) for c in local_cids} if cpr > 1 else None
+
+    def local_flats():
+        return {rank: model.flat.data} if cpr == 1 else dict(client_flats)
 
     def aggregate(dump=None, keep=False):
         if world > 1:
             if keep:                                                       # inputs of the self-validation below
                 agg_state["g_before"] = global_model.flat.data.clone()
-                agg_state["client"] = model.flat.data.clone()
+                agg_state["client"] = torch.stack([f.clone() for f in local_flats().values()])
             if dump:
                 os.makedirs(dump, exist_ok=True)
-                torch.save(model.flat.detach().cpu(), os.path.join(dump, f"client{rank}.pt"))
+                for c, f in local_flats().items():
+                    torch.save(f.detach().cpu(), os.path.join(dump, f"client{c}.pt"))
                 if rank == 0:
                     torch.save(global_model.flat.detach().cpu(), os.path.join(dump, "global_before.pt"))
-            agg.aggregate(global_model, plan, {rank: model.flat.data}, rank=rank, world=world, comm=comm)
+            agg.aggregate(global_model, plan, local_flats(), rank=rank, world=world, comm=comm)
             agg_state["g_after"] = global_model.flat.data
             if dump and rank == 0:
                 torch.save(global_model.flat.detach().cpu(), os.path.join(dump, "global_after.pt"))
                 json.dump(dict(keys=keys, coef={k: [coef[k][i] for i in cids] for k in keys}, segments={k: [s["offset"], s["numel"]] for k, s in model.segments.items()}),
                           open(os.path.join(dump, "plan.json"), "w"))
             model.flat.data.copy_(global_model.flat.data)                  # next round's download(): device-to-device
+            if cpr > 1:
+                for f in client_flats.values():
+                    f.copy_(global_model.flat.data)
             model._bump()
             model.prepare_weights(force=True)                              # ... and its bf16 compute weights
+
+    def train(k):
+        """k steps of every local client (one client per rank: this rank's; else the rank's queue, each from its own weights with a fresh
+        optimizer state, fedavgclient.py:63)."""
+        if cpr == 1:
+            for _ in range(k):
+                step()
+            return
+        for c in local_cids:
+            model.flat.data.copy_(client_flats[c])
+            model._bump()
+            model.prepare_weights(force=True)
+            m1.zero_(); m2.zero_()
+            step_no[0] = 0
+            for _ in range(k):
+                step(batch=client_batches[c])
+            client_flats[c].copy_(model.flat.data)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    train(a.warmup)
     aggregate()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    train(a.steps)
     t_enq = time.perf_counter() - t0        # host time to enqueue the steps (launch-bound if close to dt)
     torch.cuda.synchronize()
     t_steps = time.perf_counter() - t0
@@ -540,9 +588,10 @@ def main():
         same = all(bool(torch.equal(all_cs[0], c)) for c in all_cs)
         # (b) rank 0 recomputes a 1-MB slice from the gathered client slices with plain torch ops (no oracle, no library kernel)
         nsl = min(262144, n)
-        mine = agg_state["client"][:nsl].contiguous()
-        sl = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(sl, mine)
+        mine = agg_state["client"][:, :nsl].contiguous()                   # [clients of this rank, slice]
+        gathered_sl = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered_sl, mine)
+        sl = [gathered_sl[j % world][j // world] for j in range(len(cids))]     # client j trained on rank j % world, as its (j // world)-th
         ok_slice = True
         if rank == 0:
             exp = torch.zeros(nsl, device=dev, dtype=torch.float64)
@@ -553,7 +602,7 @@ def main():
                 e = min(o + ln, nsl)
                 w = plan.weights[sidx].double()
                 acc = w[0] * agg_state["g_before"][o:e].double()
-                for j in range(world):
+                for j in range(len(cids)):
                     so = int(plan.src_off[sidx, j])
                     if so >= 0 and float(w[1 + j]) != 0.0:
                         acc = acc + w[1 + j] * sl[j][so:so + (e - o)].double()
@@ -571,7 +620,7 @@ def main():
         if not (comm is None and comm_c is None):
             g2 = copy.deepcopy(global_model)
             g2.flat.data.copy_(agg_state["g_before"])
-            agg.aggregate(g2, plan, {rank: agg_state["client"]}, rank=rank, world=world, comm=other)
+            agg.aggregate(g2, plan, {c: agg_state["client"][j] for j, c in enumerate(local_cids)}, rank=rank, world=world, comm=other)
             d = (g2.flat.data - g_after).abs().max()
             paths_agree = bool(d <= 2e-6 * max(1.0, float(g_after.abs().max())))
         flags = torch.tensor([int(same), int(ok_slice), int(paths_agree is not False)], device=dev)
@@ -615,20 +664,21 @@ def main():
         extra = extra_legs(a, args, model, step, B, seq, dev, dt / a.steps)
 
     if rank == 0:
-        pairs = world * B * a.steps / dt
+        pairs = world * cpr * B * a.steps / dt
         out = dict(metric="img-txt pairs/sec per client round (ViT-S+BERT-mini)", value=round(pairs, 1), unit="img-txt pairs/s", n_gpus=world,
-                   steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True, scaling="weak",
+                   steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / (a.steps * cpr) * 1e3, 3), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype=a.precision, data="synthetic",
                    config=dict(workload="Flickr30k FedCola, 1 img-txt client per GPU, mome_small_patch16 (ViT-S + 12x384 text tower), "
                                         f"B={B}, 224x224 RGB, {seq}-token captions, vocab 7732, AdamW lr 1e-4, drop-path {a.dropout:g}"
                                         + (f", FedProx mu={a.fedprox_mu}" if a.fedprox_mu > 0 else "")
                                         + (", batches from host memory through the device prefetcher" if a.h2d else ""),
-                               global_batch=world * B, parallelism=f"{world} concurrent clients + RCCL FedAvg all-reduce"),
+                               global_batch=world * B, parallelism=f"{world} concurrent clients + RCCL FedAvg all-reduce"
+                               + (f"; {cpr} sampled clients queued per GPU, pre-accumulated locally before the all-reduce" if cpr > 1 else "")),
                    step_mfma_frac=round(pairs * PAIR_GFLOP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
                    step_hbm_frac=round(STEP_ALG_GB * (pairs / (world * B)) / PEAK_HBM_GBS, 4),
                    last_loss=round(loss, 4), enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3),
                    aggregate_ms=round((dt - t_steps) * 1e3, 3), allreduce_bytes=(4 * n if world > 1 else 0),
-                   per_rank_ms_per_step=[round(x / a.steps * 1e3, 3) for x in per_rank],
+                   per_rank_ms_per_step=[round(x / (a.steps * cpr) * 1e3, 3) for x in per_rank],
                    aggregate_path=("none (1 client)" if world == 1 else ("C ABI fc_aggregate: HIP blend + ncclAllReduce" if comm is not None else
                                    "HIP blend + torch.distributed.all_reduce (" + dist.get_backend() + ")")))
         if world > 1:
@@ -639,6 +689,13 @@ def main():
             out.update(selfcheck)
             if cabi_error:
                 out["cabi_comm_error"] = cabi_error
+            # what answers SURVEY 8(e)'s ring-vs-direct question from this one line: the message, the time, and the RCCL knobs in force
+            out["clients_per_rank"] = cpr
+            out["allreduce_message_MB"] = round(4 * n / 1e6, 1)
+            out["rccl_env"] = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))} or "defaults (no NCCL_* / RCCL_* variable set)"
+            out["xgmi_estimate_ms"] = dict(ring_one_link=round(2 * (world - 1) / world * 4 * n / 153e9 * 1e3, 2),
+                                           direct_all_links=round(2 * (world - 1) / world * 4 * n / (153e9 * max(world - 1, 1)) * 1e3, 2),
+                                           note="2 (N-1)/N x message over one 153-GB/s link (ring) or over all N-1 links (direct reduce-scatter + all-gather)")
         out.update(extra)
         if drop_line is not None:
             out["dropout_0p1"] = drop_line

@@ -57,6 +57,30 @@ def test_bench_two_ranks_one_device_matches_sequential_blend(tmp_path, agg):
         pytest.skip("checked on the torch path: RCCL refuses two ranks on one device, the C-ABI communicator needs two GPUs")
 
 
+def test_bench_more_sampled_clients_than_ranks_queue_and_preaccumulate(tmp_path):
+    """Four sampled clients on two ranks (--clients-per-rank 2: positions p % world, fedavgserver.py:310-311): each rank trains its two
+    clients one after the other and blends both into its partial before the one all-reduce; the global model equals the oracle's
+    sequential blend of the four dumped clients, and the line's own checks hold."""
+    from oracle import aggregate_oracle as AO
+    p, d = _run(tmp_path, ["--agg", "torch", "--clients-per-rank", "2"])
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["clients_per_rank"] == 2 and rec["agg_checksum_agree"] is True and rec["agg_all_ranks_equal"] is True
+    assert rec["allreduce_message_MB"] > 180 and "ring_one_link" in rec["xgmi_estimate_ms"] and rec["rccl_env"]
+    plan = json.load(open(os.path.join(d, "plan.json")))
+    g0, g1 = torch.load(os.path.join(d, "global_before.pt")), torch.load(os.path.join(d, "global_after.pt"))
+    cl = [torch.load(os.path.join(d, f"client{c}.pt")) for c in range(4)]
+    assert all(not torch.equal(cl[0], cl[c]) for c in (1, 2, 3))
+    seg = plan["segments"]
+    view = lambda flat: {k: flat[seg[k][0]: seg[k][0] + seg[k][1]] for k in plan["keys"]}
+    coef = {k: {i: plan["coef"][k][i] for i in range(4)} for k in plan["keys"]}
+    exp = AO.sequential_blend(view(g0), {c: view(cl[c]) for c in range(4)}, [0, 1, 2, 3], coef)
+    got = view(g1)
+    for k, v in exp.items():
+        err = float((got[k] - v).abs().max())
+        assert err <= 3e-6 * max(1.0, float(v.abs().max())), (k, err)
+
+
 def test_bench_gpus_flag_without_enough_devices_fails_loudly(tmp_path):
     if torch.cuda.device_count() >= 64:
         pytest.skip("box has 64 GPUs")

@@ -4,7 +4,7 @@
 #                                  gpurun -- 'bash tools/ab_bench.sh fedcola_amd/libfc_base.so'
 BASE=${1:-fedcola_amd/libfc_base.so}; R=${2:-3}
 for i in $(seq $R); do
-  a=$(FC_LIB_PATH=$PWD/$BASE python bench.py --no-cpu-baseline --no-roofline --no-dropout-line --steps 100 --warmup 10 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
-  b=$(python bench.py --no-cpu-baseline --no-roofline --no-dropout-line --steps 100 --warmup 10 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
+  a=$(FC_LIB_PATH=$PWD/$BASE python bench.py --no-cpu-baseline --no-roofline --no-dropout-line --no-extra-legs --steps 100 --warmup 10 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
+  b=$(python bench.py --no-cpu-baseline --no-roofline --no-dropout-line --no-extra-legs --steps 100 --warmup 10 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
   echo "round $i: base $a   new $b"
 done
