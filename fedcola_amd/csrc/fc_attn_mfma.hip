@@ -397,211 +397,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
 // its exponent VALU work, with 2 waves per SIMD and one workgroup per CU (114 KB of LDS) there is nothing to overlap them with, and 384
 // workgroups on 256 CUs leave the second round half empty.  The exponent is folded to one fma + v_exp_f32 here (-2.7 us); the same fold made
 // the 32-row two-body kernel 3 us SLOWER stand-alone (39.1 vs 36.1 us, fewer instructions, same registers) and the 16-row one 1 us faster.
-#ifdef FC_PROBES
-// ONE workgroup of 8 waves per (batch, head) with Q, K, V and dO tiles all resident in LDS (4 x 28 KB at N = 197): every input row is read
-// from HBM once (the two-body form above stages K, V in one workgroup and Q, dO in another and streams the other pair as fragments:
-// 126 MB of traffic per image-tower launch at B = 64 against 77 MB here), delta = rowsum(dO * O) is formed once, and a wave takes one
-// 32-query block of dQ and then one 32-key block of dK / dV (7 blocks of each at N = 197: one pass of the 8 waves per phase).
-#define AB_WAVES 8
-__device__ __forceinline__ uint4 keep(bool in, uint4 v) { return make_uint4(in ? v.x : 0u, in ? v.y : 0u, in ? v.z : 0u, in ? v.w : 0u); }
-template <int NF>
-__global__ void __launch_bounds__(64 * AB_WAVES, 2) k_attn_bwd_fused(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                                     const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale, int skip) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NP = 16 * NF, NT = 64 * AB_WAVES;
-  char* Qs = smem;
-  char* Ks = smem + NP * 128;
-  char* Vs = smem + 2 * NP * 128;
-  char* Ds = smem + 3 * NP * 128;
-  float* lse_s = (float*)(smem + 4 * NP * 128);
-  float* del_s = lse_s + NP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cl = lane & 15;
-  const float sc2 = scale * 1.4426950408889634f;   // exp(scale s - lse) = 2^(s sc2 - lse log2 e)
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const long D3 = 3L * H * 64, Dm = (long)H * 64;
-  const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
-  const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
-  const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
-  {   // ONE memory round trip for the whole workgroup: all five operand loads of a thread are in flight before its first LDS write.
-      // delta = rowsum(dO * O): a row's 8 chunks sit in 8 consecutive lanes
-    constexpr int IT = (NP * 8 + NT - 1) / NT;
-    uint4 q_[IT], k_[IT], v_[IT], d_[IT], o_[IT];
-    float ls_[IT];
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int idx = tid + NT * i, row = idx >> 3, c = idx & 7;
-      const int rc = row < N ? row : N - 1;
-      const bf16_t* pr = base + (size_t)rc * D3 + c * 8;
-      q_[i] = *(const uint4*)pr;
-      k_[i] = *(const uint4*)(pr + Dm);
-      v_[i] = *(const uint4*)(pr + 2 * Dm);
-      d_[i] = *(const uint4*)(dobase + (size_t)rc * Dm + c * 8);
-      o_[i] = *(const uint4*)(obase + (size_t)rc * Dm + c * 8);
-      ls_[i] = lse[((size_t)b * H + h) * N + rc];
-    }
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int idx = tid + NT * i, row = idx >> 3, c = idx & 7;
-      const bool in = row < N;
-      const uint4 dv4 = keep(in, d_[i]);
-      float d = dot8(__builtin_bit_cast(bf16x8, dv4), __builtin_bit_cast(bf16x8, o_[i]));
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      d += __shfl_xor(d, 4, 64);
-      if (NP * 8 % NT == 0 || row < NP) {
-        const int off = at_off(row, c);
-        *(uint4*)(Qs + off) = keep(in, q_[i]);
-        *(uint4*)(Ks + off) = keep(in, k_[i]);
-        *(uint4*)(Vs + off) = keep(in, v_[i]);
-        *(uint4*)(Ds + off) = dv4;
-        if (c == 0) {
-          del_s[row] = d;
-          lse_s[row] = in ? ls_[i] * 1.4426950408889634f : 1e30f;   // padded queries: P = exp(. - 1e30) = 0
-        }
-      }
-    }
-  }
-  __syncthreads();
-  bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
-  // ---- phase 1: dQ of the query pair `wave` (rows 32 qp .. 32 qp + 31)
-  for (int qp = wave; qp < NF / 2 && !(skip & 1); qp += AB_WAVES) {
-    if (qp * 32 >= N) break;
-    bf16x8 qf[2][2], dof[2][2];
-    float dl[2], lq[2];
-    int qrow[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      qrow[u] = (2 * qp + u) * 16 + cl;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        qf[u][ks] = row_frag(Qs, (2 * qp + u) * 16, ks, lane);
-        dof[u][ks] = row_frag(Ds, (2 * qp + u) * 16, ks, lane);
-      }
-      dl[u] = del_s[qrow[u]];
-      lq[u] = lse_s[qrow[u]];
-    }
-    f32x4 dq[2][4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int db = 0; db < 4; ++db) dq[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int ss = 0; ss < NF / 2; ++ss) {                  // key pair: keys 32 ss .. 32 ss + 31
-      bf16x8 kf[2][2], vf[2][2];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { kf[hh][ks] = row_frag(Ks, (2 * ss + hh) * 16, ks, lane); vf[hh][ks] = row_frag(Vs, (2 * ss + hh) * 16, ks, lane); }
-      bf16x8 bfg[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        f32x4 ds[2];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            st = MFMA(kf[hh][ks], qf[u][ks], st);          // S^T[key][q]
-            dpt = MFMA(vf[hh][ks], dof[u][ks], dpt);       // dP^T[key][q]
-          }
-#pragma unroll
-          for (int x = 0; x < 4; ++x) ds[hh][x] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[x], sc2, -lq[u])) * (dpt[x] - dl[u]);
-        }
-        bfg[u] = pack8(ds[0], ds[1]);                      // B[k = key(8g+j)][col = q = cl]
-      }
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const bf16x8 kt = tr_frag(Ks, 32 * ss, db * 16, lane);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) dq[u][db] = MFMA(kt, bfg[u], dq[u][db]);   // dQ^T[d = 16db+4g+x][q = cl]
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (qrow[u] < N) {   // a lane owns 4 consecutive head dims of its query row: 8-byte stores
-        bf16_t* p = dbase + (size_t)qrow[u] * D3 + 4 * g;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-          *(uint2*)(p + db * 16) = make_uint2(f2bf2(dq[u][db][0] * scale, dq[u][db][1] * scale), f2bf2(dq[u][db][2] * scale, dq[u][db][3] * scale));
-      }
-  }
-  // ---- phase 2: dK / dV of the key pair `wave` (keys 32 kp .. 32 kp + 31)
-  for (int kp = wave; kp < NF / 2 && !(skip & 2); kp += AB_WAVES) {
-    if (kp * 32 >= N) break;
-    bf16x8 kfb[2][2], vfb[2][2];
-    int krow[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      krow[u] = (2 * kp + u) * 16 + cl;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) { kfb[u][ks] = row_frag(Ks, (2 * kp + u) * 16, ks, lane); vfb[u][ks] = row_frag(Vs, (2 * kp + u) * 16, ks, lane); }
-    }
-    f32x4 dv[2][4], dk[2][4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int db = 0; db < 4; ++db) { dv[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 1
-    for (int qp = 0; qp < NF / 2; ++qp) {                  // query pair: rows 32 qp .. 32 qp + 31
-      bf16x8 qf[2][2], df[2][2];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { qf[hh][ks] = row_frag(Qs, (2 * qp + hh) * 16, ks, lane); df[hh][ks] = row_frag(Ds, (2 * qp + hh) * 16, ks, lane); }
-      float lv[2][4], dl[2][4];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const float4 l4 = *(const float4*)(lse_s + (2 * qp + hh) * 16 + 4 * g), d4 = *(const float4*)(del_s + (2 * qp + hh) * 16 + 4 * g);
-        lv[hh][0] = l4.x; lv[hh][1] = l4.y; lv[hh][2] = l4.z; lv[hh][3] = l4.w;
-        dl[hh][0] = d4.x; dl[hh][1] = d4.y; dl[hh][2] = d4.z; dl[hh][3] = d4.w;
-      }
-      bf16x8 pa[2], dsa[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        f32x4 P[2], dS[2];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            sa = MFMA(qf[hh][ks], kfb[u][ks], sa);         // S[q = 4g+x][key = cl]
-            dpa = MFMA(df[hh][ks], vfb[u][ks], dpa);       // dP[q][key]
-          }
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[x], sc2, -lv[hh][x]));
-            P[hh][x] = p;
-            dS[hh][x] = p * (dpa[x] - dl[hh][x]);
-          }
-        }
-        pa[u] = pack8(P[0], P[1]);                         // B[k = q(8g+j)][col = key = cl]
-        dsa[u] = pack8(dS[0], dS[1]);
-      }
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const bf16x8 dt = tr_frag(Ds, 32 * qp, db * 16, lane), qt = tr_frag(Qs, 32 * qp, db * 16, lane);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          dv[u][db] = MFMA(dt, pa[u], dv[u][db]);          // dV^T[d = 16db+4g+x][key = cl]
-          dk[u][db] = MFMA(qt, dsa[u], dk[u][db]);         // dK^T[d][key]
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (krow[u] < N) {   // a lane owns 4 consecutive head dims of its key row: 8-byte stores
-        bf16_t* pk = dbase + (size_t)krow[u] * D3 + Dm + 4 * g;
-        bf16_t* pv = dbase + (size_t)krow[u] * D3 + 2 * Dm + 4 * g;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          *(uint2*)(pk + db * 16) = make_uint2(f2bf2(dk[u][db][0] * scale, dk[u][db][1] * scale), f2bf2(dk[u][db][2] * scale, dk[u][db][3] * scale));
-          *(uint2*)(pv + db * 16) = make_uint2(f2bf2(dv[u][db][0], dv[u][db][1]), f2bf2(dv[u][db][2], dv[u][db][3]));
-        }
-      }
-  }
-}
-
-#endif   // FC_PROBES
+// (A single-pass form -- one 8-wave workgroup per (batch, head) with Q, K, V and dO all resident in LDS, every input read once -- was built
+// and measured slower, 41.7 vs 36.1 us: profiles/r04/removed_experiments.patch, profiles/r03/attn_bwd_fused.txt.)
 
 // ======================================================================== launchers
 static int pick_nf(int N) { return N <= 32 ? 2 : N <= 64 ? 4 : N <= 224 ? 14 : N <= 256 ? 16 : 0; }
@@ -659,36 +456,12 @@ int fc_attn_fwd_mfma(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int
   return 1;
 }
 
-#ifdef FC_PROBES
-template <int NF>
-static int launch_bwd_fused(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, bf16_t* dqkv, int B, int N, int H, float scale,
-                            hipStream_t s) {
-  const int lds = 4 * 16 * NF * 128 + 2 * 16 * NF * 4;
-  auto kb = k_attn_bwd_fused<NF>;
-  static bool done = false;
-  if (!done) {
-    FC_CHECK_HIP(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    done = true;
-  }
-  static const int skip = fc_knob("FC_ATTN_BWD_SKIP", 0);   // tools build: time the staging / dQ / dK-dV phases apart
-  hipLaunchKernelGGL(kb, dim3(B * H), dim3(64 * AB_WAVES), lds, s, qkv, o, dout, lse, dqkv, B, N, H, scale, skip);
-  FC_LAUNCH_CHECK();
-  return 0;
-}
-#endif
 
 int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv, int B, int N, int H,
                      int d, float scale, hipStream_t s) {
   if (FC_ABLATED("attn")) return 0;
   (void)delta;   // recomputed in-kernel
   if (d != 64 || ((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)o & 15)) return 1;
-#ifdef FC_PROBES
-  static const int fused = fc_knob("FC_ATTN_BWD_FUSED", 0);
-  if (fused) {           // experiment: every operand tile resident, one pass over the inputs
-    if (pick_nf(N) == 14) return launch_bwd_fused<14>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
-    if (pick_nf(N) == 16) return launch_bwd_fused<16>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
-  }
-#endif
   // 16-row blocks per wave at twice the waves (8 per workgroup for the image sequences: 110 VGPRs, 4 waves per SIMD) instead of 32-row
   // blocks at 2 waves per SIMD (206 VGPRs): twice the LDS fragment reads per MFMA -- the LDS is 13 % busy -- for twice the waves to
   // cover the MFMA -> exponent -> MFMA dependency chain with: 36.0 -> 33.0 us at B = 64, N = 197, 32.0 with the exponent folded into one fma +

@@ -152,29 +152,6 @@ struct GemmProb { const bf16_t* A; const bf16_t* B; void* C; long lda, ldb, ldc;
 struct GemmGroup { GemmProb p[2]; int N, K, tiles_n, tiles0, ntiles; };
 int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t s);
 
-// ---- large-tile grouped NT GEMM (fc_gemm_big.hip): C_p[M_p,N] = A_p[M_p,K] . W_p[N,K]^T for up to two row sets in one launch
-struct FcGemmProb {
-  const bf16_t* A; const bf16_t* W; bf16_t* C;
-  const float* bias;        // [N]
-  const void* res;          // residual [M, ldc] (bf16)
-  void* preact;             // GELU_SG: gelu'(acc + bias) goes here, gelu(acc + bias) to C
-  const void* mul_in;       // MUL: C = acc * mul_in
-  const float* rowscale;    // RES_SCALE: per-sample multiplier of (acc + bias) before the residual add
-  long lda, ldw, ldc;
-  int M, rows_per_sample;
-};
-struct FcGemmGrouped { FcGemmProb p[2]; int nprob, N, K, epi; };
-int fc_gemm_grouped_epi(const GemmEpi& e);   // epilogue code of this kernel for a GemmEpi (-1: not covered)
-// returns 1 when the shapes are not covered (K % 64, N % 8, alignment); force_bm: 0 = heuristic, 128 / 256 = tile rows
-int fc_gemm_nt_grouped(const FcGemmGrouped& g, hipStream_t s, int force_bm = 0);
-// transposed bf16 copies of the linears' compute weights (dst[in][out] = src[out][in]) for the dX products
-struct FcTranspose { int64_t src, dst; int32_t out, in; };
-int fc_transpose_linears(const FcTranspose* tab_dev, int n, const bf16_t* src, bf16_t* dst, hipStream_t s);
-
-// weight-stationary form for K <= 384 (fc_gemm_ws.hip); returns 1 when the shape / epilogue is not covered
-int fc_gemm_ws(int kind, const bf16_t* A, long lda, const bf16_t* W, long ldw, bf16_t* C, long ldc, int M, int N, int K, const GemmEpi& epi,
-               hipStream_t s);
-
 // grouped weight-gradient GEMM: C[M,N] (fp32) = A[K,M]^T . B[K,N], bias_grad[M] = column sums of A (may be null)
 struct FcTnProblem {
   const bf16_t* A;

@@ -16,7 +16,6 @@
 //   KR tile [64 k][128 cols]  (256 B rows): 32-B unit u of row k lives at unit u ^ (((k>>3)&1)<<2 | (k&3)); fragments by
 //   ds_read_b64_tr_b16 (the CDNA4 transposing LDS read), two per 8-k fragment.
 // Block ids are remapped so that the tiles sharing an A row-panel run on the same XCD (private L2).
-// The weight-stationary kernels for K <= 384 live in fc_gemm_ws.hip.
 #include <stdlib.h>
 #include <string.h>
 
@@ -734,14 +733,5 @@ int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm,
   GemmGroup g{};
   g.p[0] = GemmProb{A, Bm, C, lda, ldb, ldc, M, epi_in};
   g.N = N; g.K = K;
-#ifdef FC_PROBES
-  // FC_GEMM_WS (tools build): 1 weight-stationary kernel wherever it applies (K = 384); 2 only for N >= 1024; 3 additionally only for
-  // M >= 8192.  Stand-alone it is 18-23 % faster on the N = 1536 shapes, inside the client step 0-4 % slower: DESIGN.md section 3.
-  static const int use_ws = getenv("FC_GEMM_WS") ? atoi(getenv("FC_GEMM_WS")) : 0;
-  if (use_ws && dtC == FC_BF16 && kind != FC_GEMM_TN && gemm_prob_ok(kind, g.p[0], N, K) && (use_ws == 1 || N >= 1024) && (use_ws < 3 || M >= 8192)) {
-    int r = fc_gemm_ws(kind, A, lda, Bm, ldb, (bf16_t*)C, ldc, M, N, K, epi_in, s);
-    if (r <= 0) return r;
-  }
-#endif
   return fc_gemm_mfma_grouped(kind, dtC, g, 1, s);
 }

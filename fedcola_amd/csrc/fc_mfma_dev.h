@@ -1,4 +1,4 @@
-// Device-side building blocks shared by the MFMA GEMM kernels (fc_mfma.hip, fc_gemm_ws.hip): LDS tile images and their
+// Device-side building blocks shared by the MFMA GEMM kernels (fc_mfma.hip, fc_gemm_dw.hip): LDS tile images and their
 // swizzles, LDS-DMA staging through buffer descriptors, fragment reads, 8-wide epilogue loads / stores.
 #pragma once
 #include "fc_kernels.h"

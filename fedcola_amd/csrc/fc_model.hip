@@ -509,16 +509,6 @@ struct Ctx {
   const void* W(int64_t off) const { return wc + (size_t)off * es; }
   // Y[M,N] = X[M,K] . W[N,K]^T
   int gemm_fwd(const void* X, const void* Wt, void* Y, int M, int N, int K, const GemmEpi& e) const {
-#ifdef FC_PROBES
-    static const int big = fc_knob("FC_GEMM_BIG", 0);   // experiment: large-tile kernel for the forward linears
-    if (big && dt == FC_BF16 && fc_gemm_grouped_epi(e) >= 0) {
-      FcGemmGrouped g{};
-      g.nprob = 1; g.N = N; g.K = K; g.epi = fc_gemm_grouped_epi(e);
-      g.p[0] = FcGemmProb{(const bf16_t*)X, (const bf16_t*)Wt, (bf16_t*)Y, e.bias, e.res, e.preact, e.gelu_in, e.rowscale, (long)K, (long)K, (long)N, M, e.rows_per_sample};
-      int r = fc_gemm_nt_grouped(g, s, big);
-      if (r <= 0) return r;
-    }
-#endif
     if (dt == FC_BF16) {
       int r = fc_gemm_mfma(FC_GEMM_NT, FC_BF16, (const bf16_t*)X, K, (const bf16_t*)Wt, K, Y, N, M, N, K, e, s);
       if (r <= 0) return r;

@@ -204,37 +204,3 @@ def test_cast_bf16_rne():
     L().check(L().lib().fc_k_cast(1, P(dev(x)), P(y), 1000, S()))
     torch.cuda.synchronize()
     assert torch.equal(y.cpu(), x.to(torch.bfloat16))
-
-
-def test_weight_stationary_gemm_opt_in_path(tmp_path):
-    """The K = 384 weight-stationary kernels (fc_gemm_ws.hip) are an experiment kept in the tools build only (-DFC_PROBES,
-    FC_PROBES_LIB=1 FC_GEMM_WS=1, read once per process): run the GEMM and model parity tests in a child process with the switch on,
-    so that the path stays correct although the product step does not take it (faster stand-alone on the
-    N = 1536 shapes, not inside the multi-stream step)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not os.path.exists(os.path.join(root, "fedcola_amd", "libfedcola_hip_probes.so")):
-        pytest.skip("tools build (python -m fedcola_amd.build --probes) not present")
-    env = dict(os.environ, FC_GEMM_WS="1", FC_PROBES_LIB="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_kernels.py"),
-                        os.path.join(root, "tests", "test_gpu_bf16_parity.py"), "-k", "test_gemm or layer_by_layer"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-
-
-def test_fused_attention_backward_opt_in_path():
-    """The single-pass attention backward (k_attn_bwd_fused, Q / K / V / dO all resident in LDS) is an experiment kept in the tools
-    build only (FC_PROBES_LIB=1 FC_ATTN_BWD_FUSED=1; slower stand-alone than the two-body kernel, fc_attn_mfma.hip): the attention
-    parity cases run against it in a child process so that the record stays a correct kernel."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not os.path.exists(os.path.join(root, "fedcola_amd", "libfedcola_hip_probes.so")):
-        pytest.skip("tools build (python -m fedcola_amd.build --probes) not present")
-    env = dict(os.environ, FC_ATTN_BWD_FUSED="1", FC_PROBES_LIB="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_kernels.py"),
-                        "-k", "test_attention"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
