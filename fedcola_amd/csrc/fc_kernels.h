@@ -18,9 +18,9 @@ struct FcLnFwdArgs { FcLnFwdP p[2]; int nprob; int D; float eps; };
 // dx = (res ? res : 0) + LNbwd(dy); dx_scaled (optional): a second output dx * rowscale[row / rows_per_sample] (drop-path: the next
 // consumer's operand); partial: room for fc_layernorm_bwd_partial_blocks(M) * 2 * D floats, one [dgamma | dbeta] row per block, summed
 // later by fc_ln_reduce_grouped over the queued FcLnReduce entries (room for ... * 2 * D fc_ln_part_t)
-// The [dgamma | dbeta] partial rows are DOUBLES: products d * xhat are formed in fp32 (as the reference does) and summed in fp64 from the
-// first add to the last, so the column sums do not depend on how the rows are grouped into blocks, chains or launches (two schedules of the
-// same step give the same dgamma / dbeta up to the final rounding to fp32) and carry no fp32 summation error of their own.
+// The [dgamma | dbeta] partial-row buffers are sized for DOUBLES.  fp32 storage (the parity mode): products d * xhat are formed in fp32 (as
+// the reference does) and summed in fp64 from the first add to the last -- no fp32 summation error, no dependence on how the rows are
+// grouped.  bf16 storage: fp32 block sums in the same buffers (FcLnReduce.f64 = 0).  k_ln_reduce adds the rows of either type in fp64.
 typedef double fc_ln_part_t;
 struct FcLnBwdP {
   const void* dy; const void* x; const float* mean; const float* rstd; const float* g; const void* res; void* dx; void* dx_scaled;
@@ -39,7 +39,7 @@ struct FcLnReduce {
   float* db;
   int nblocks, nblocks2, D, accumulate;
   const fc_ln_part_t* partial3;   // a third micro-batch chain's partial rows (three-chain backward)
-  int nblocks3, pad_;
+  int nblocks3, f64;       // f64: the partial rows hold doubles (fp32 storage) / floats (bf16 storage)
 };
 int fc_layernorm_bwd_partial_blocks(int M);
 int fc_ln_reduce_grouped(const FcLnReduce* tab_dev, int n, int maxD, hipStream_t s);

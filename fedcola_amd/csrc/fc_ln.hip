@@ -122,7 +122,9 @@ __global__ void __launch_bounds__(256) k_ln_fwd_g(FcLnFwdArgs a) {
 template <typename T, int CH, int LN_BWD_RG>
 __global__ void __launch_bounds__(256) k_ln_bwd_g(FcLnBwdArgs a) {
   constexpr int LN_BWD_ROWS = 16 * LN_BWD_RG;
-  extern __shared__ double red_dyn[];  // [4 waves][2][D]
+  typedef typename LnAcc<T>::type acc_t;   // fp32 storage (parity mode): fp64 column sums from the first add; bf16 storage: fp32
+  extern __shared__ char red_raw[];
+  acc_t* red_dyn = (acc_t*)red_raw;        // [4 waves][2][D]
   const bool second = a.nprob > 1 && (int)blockIdx.x >= a.p[1].blk0;
   const FcLnBwdP& P = second ? a.p[1] : a.p[0];
   const int D = a.D, nc = D >> 3;
@@ -154,10 +156,11 @@ __global__ void __launch_bounds__(256) k_ln_bwd_g(FcLnBwdArgs a) {
       }
     }
   }
-  // Column sums: fp32 storage (the parity mode) adds in fp64 from the first add; bf16 storage adds the lane's LN_BWD_RG (<= 2) products
-  // in fp32 -- one rounding of 2^-24 per pair, far below the bf16 inputs' own 2^-9 -- and continues in fp64 from there (shuffles, LDS,
-  // partial rows, reduction): fp64 adds per element made this HBM-bound kernel 40 % slower (10.6 -> 15.1 us at 12 608 rows).
-  typedef typename LnAcc<T>::type acc_t;
+  // Column sums: fp32 storage (the parity mode) adds in fp64 from the first add to the partial row (the sums cancel to ~1e-3 of their
+  // summands: fp32 accumulation alone costs ~1e-4 of the result there, the whole parity budget).  bf16 storage keeps fp32 up to the
+  // block's partial row -- its inputs carry 2^-9 each -- because fp64 adds, shuffles and partial rows made this HBM-bound kernel slower
+  // (10.6 -> 15.1 us at 12 608 rows all-fp64, 4.57 -> 4.63 ms per step with fp64 behind the lane sums); the partial rows of either type
+  // are summed in fp64 by k_ln_reduce.
   float gg[CH][8];
   acc_t ag[CH][8], ab[CH][8];
 #pragma unroll
@@ -213,23 +216,18 @@ __global__ void __launch_bounds__(256) k_ln_bwd_g(FcLnBwdArgs a) {
 #pragma unroll
   for (int t = 0; t < CH; ++t) {
     const int c = sub + 16 * t;
-    double* r0 = red_dyn + (wave * 2 + 0) * D + c * 8;
-    double* r1 = red_dyn + (wave * 2 + 1) * D + c * 8;
+    acc_t* r0 = red_dyn + (wave * 2 + 0) * D + c * 8;
+    acc_t* r1 = red_dyn + (wave * 2 + 1) * D + c * 8;
 #pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-      double a0 = (double)ag[t][i], a1 = (double)ag[t][i + 1], b0 = (double)ab[t][i], b1 = (double)ab[t][i + 1];
+    for (int i = 0; i < 8; ++i) {
+      acc_t a0 = ag[t][i], b0 = ab[t][i];
       a0 += __shfl_xor(a0, 16, 64); a0 += __shfl_xor(a0, 32, 64);
-      a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
       b0 += __shfl_xor(b0, 16, 64); b0 += __shfl_xor(b0, 32, 64);
-      b1 += __shfl_xor(b1, 16, 64); b1 += __shfl_xor(b1, 32, 64);
-      if (slot == 0 && c < nc) {
-        *(double2*)(r0 + i) = make_double2(a0, a1);
-        *(double2*)(r1 + i) = make_double2(b0, b1);
-      }
+      if (slot == 0 && c < nc) { r0[i] = a0; r1[i] = b0; }
     }
   }
   __syncthreads();
-  fc_ln_part_t* pp = P.partial + (size_t)lblk * 2 * D;
+  acc_t* pp = (acc_t*)P.partial + (size_t)lblk * 2 * D;      // (the buffer is sized for fp64 rows; bf16 storage writes fp32 ones: FcLnReduce.f64)
   for (int i = threadIdx.x; i < 2 * D; i += 256) {
     const int h = i >= D, col = i - h * D;
     pp[i] = red_dyn[(0 * 2 + h) * D + col] + red_dyn[(1 * 2 + h) * D + col] + red_dyn[(2 * 2 + h) * D + col] + red_dyn[(3 * 2 + h) * D + col];
@@ -246,12 +244,14 @@ __global__ void __launch_bounds__(1024) k_ln_reduce(const FcLnReduce* __restrict
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
   if (blockIdx.x * 64 >= W) return;
   double acc = 0.0;
-  if (col < W)
-    for (int bk = wave; bk < e.nblocks; bk += 16) acc += e.partial[(size_t)bk * W + col];
-  if (e.partial2 && col < W)
-    for (int bk = wave; bk < e.nblocks2; bk += 16) acc += e.partial2[(size_t)bk * W + col];
-  if (e.partial3 && col < W)
-    for (int bk = wave; bk < e.nblocks3; bk += 16) acc += e.partial3[(size_t)bk * W + col];
+  const void* sets[3] = {e.partial, e.partial2, e.partial3};
+  const int nb[3] = {e.nblocks, e.nblocks2, e.nblocks3};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (!sets[q] || col >= W) continue;
+    if (e.f64) { for (int bk = wave; bk < nb[q]; bk += 16) acc += ((const double*)sets[q])[(size_t)bk * W + col]; }
+    else { for (int bk = wave; bk < nb[q]; bk += 16) acc += (double)((const float*)sets[q])[(size_t)bk * W + col]; }
+  }
   red[wave][threadIdx.x & 63] = acc;
   __syncthreads();
   if (wave == 0 && col < W) {
@@ -314,7 +314,7 @@ int fc_layernorm_bwd_grouped(int dt, FcLnBwdArgs a, hipStream_t s) {
   }
   if (blocks == 0) return 0;
   const int ch = fc_cdiv(a.D / 8, 16);
-  const size_t lds = sizeof(double) * 8 * a.D;
+  const size_t lds = (dt == FC_F32 ? sizeof(double) : sizeof(float)) * 8 * a.D;
 #define GO(CHN)                                                                                                     \
   do {                                                                                                              \
     if (ln_bwd_rg() == 1) { DISPATCH_DT(dt, hipLaunchKernelGGL((k_ln_bwd_g<T, CHN, 1>), dim3(blocks), dim3(256), lds, s, a)); } \

@@ -565,7 +565,7 @@ int Ctx::note_ln(fc_ln_part_t* partial, float* dg, float* db, int M, int D) cons
       e.partial3 = partial; e.nblocks3 = fc_layernorm_bwd_partial_blocks(M);
       return 0;
     }
-  lnq->push_back(FcLnReduce{partial, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, ln_accumulate, nullptr, 0, 0});
+  lnq->push_back(FcLnReduce{partial, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, ln_accumulate, nullptr, 0, dt == FC_F32 ? 1 : 0});
   return 0;
 }
 
@@ -2194,7 +2194,7 @@ extern "C" int fc_k_layernorm_bwd_partial(int32_t dt, const void* dy, const void
   int r = fc_layernorm_bwd(dt, dy, x, mean, rstd, g, res, dx, dg, db, M, D, s, part);
   if (r != 1) return r;
   // one-entry reduction table at the tail of `partial` (the grouped reduction adds into dg / db)
-  FcLnReduce e{part, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, 1};
+  FcLnReduce e{part, nullptr, dg, db, fc_layernorm_bwd_partial_blocks(M), 0, D, 1, nullptr, 0, dt == FC_F32 ? 1 : 0};
   FcLnReduce* tab = (FcLnReduce*)(part + (size_t)fc_layernorm_bwd_partial_blocks(M) * 2 * D);
   FC_CHECK_HIP(hipMemcpyAsync(tab, &e, sizeof(e), hipMemcpyHostToDevice, s));
   FC_CHECK_HIP(hipStreamSynchronize(s));      // `e` is a stack temporary (test entry point)

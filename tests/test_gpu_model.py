@@ -149,17 +149,16 @@ def test_microbatch_chains_do_not_change_the_result(tmp_path, kind, B):
         err = float((out["1"][k] - out["2"][k]).abs().max()) / scale
         # Every row-wise tensor of the step is the same bits in both schedules; what differs is the grouping of rows in the column sums.
         # matrix: weight gradients, full-batch weight-gradient problems in either schedule.  vector: the linears' biases (column sums
-        # inside those problems) and the blocks' LayerNorm weight / bias (fp64 partial rows: independent of the grouping up to the final
-        # rounding).  atomic: embedding tables, position / type rows, the shared final norm and a classification head -- summed with fp32
-        # atomics whose order is not fixed: equal up to the order of the sum (a cancelling sum reaches a few 1e-5 of its maximum).
-        cls = "atomic" if ("embeddings" in k or k.startswith(("norm.", "heads."))) else ("matrix" if out["1"][k].dim() > 1 else "vector")
+        # inside those problems) and the blocks' LayerNorm weight / bias (fp32 block partial rows of 32 rows each, added in fp64 by
+        # k_ln_reduce).  atomic: embedding tables, position / type rows, the shared final norm, a classification head and the re-param
+        # scalars -- summed with fp32 atomics whose order is not fixed: equal up to the order of the sum.
+        cls = "atomic" if ("embeddings" in k or k.startswith(("norm.", "heads.")) or k.endswith("cross_modal_scale")) else ("matrix" if out["1"][k].dim() > 1 else "vector")
         worst[cls] = max(worst[cls], (k, err), key=lambda t: t[1])
     print(f"schedule invariance {kind} B={B}: {worst}")
-    # measured (round 4, six cases): matrix 0 (the same bits), vector <= 3.3e-6 (cross_modal_scale: an atomically summed scalar product;
-    # LayerNorm weight / bias <= 1e-7), atomic <= 4.2e-7
+    # measured (round 4, six cases, two builds): matrix 0 (the same bits), vector <= 2.5e-7, atomic <= 9.6e-6 (a cross_modal_scale)
     assert worst["matrix"][1] <= 1e-7, worst["matrix"]
     assert worst["vector"][1] <= 2e-5, worst["vector"]
-    assert worst["atomic"][1] <= 2e-5, worst["atomic"]
+    assert worst["atomic"][1] <= 1e-4, worst["atomic"]
 
 
 @pytest.mark.parametrize("kind,width,dw_wide,B", [("img+txt", 128, "2", 0), ("img", 128, "2", 0), ("img+txt", 384, "2", 0), ("img+txt", 384, "1", 0),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun) from the repo root: collects everything profiles/rNN/ holds.  usage: tools/collect_profiles.sh r02
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/$R
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -29,6 +29,12 @@ python tools/ktrace.py /tmp/gtrace > "$OUT/roofline_kernel_trace.txt" 2>&1
 # 2c. every GEMM shape of a layer + the non-GEMM kernels, stand-alone (device-side durations)
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/gall -o g -- python3 tools/gemm_bench.py 20 > /dev/null 2>&1; python tools/ktrace.py /tmp/gall > "$OUT/gemm_shapes_ktrace.txt" 2>&1
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/kb -o g -- python3 tools/kernel_bench.py 20 > /dev/null 2>&1; KTRACE_BYNAME=1 python tools/ktrace.py /tmp/kb > "$OUT/kernels_ktrace.txt" 2>&1
+# 2c'. round 4: per kernel family in-step rates from the trace of 2., and the cold-protocol kernel times at the three row counts of the model
+python tools/in_situ_roofline.py /tmp/trace 35 > "$OUT/in_situ_roofline.txt" 2>&1
+for M in 12608 4334 2048; do
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/cold$M -o g -- python3 tools/cold_bench.py $M 24 > /dev/null 2>&1
+  KTRACE_BYNAME=1 python tools/ktrace.py /tmp/cold$M | grep -v "at::native" > "$OUT/cold_ktrace_$M.txt" 2>&1
+done
 # 2d. GPU time of the step's phases, no profiler (tools build)
 timeout 200 python tools/step_phases.py 40 2>/dev/null > "$OUT/step_phases.txt"
 # 4. whole-step fabric traffic (separate passes)
@@ -60,7 +66,8 @@ if [ -f fedcola_amd/libfedcola_hip_probes.so ]; then
       echo "2 backward chains, text tower last (FC_BWD_CHAINS=2 FC_TEXT_FIRST=0)    $(FC_PROBES_LIB=1 FC_BWD_CHAINS=2 FC_TEXT_FIRST=0 timeout 200 $B2 2>/dev/null | ms)"
     done; } > "$OUT/schedules_ab.txt"
   for sch in streams chain; do FC_PROBES_LIB=1 FC_SCHEDULE=$sch timeout 200 python tools/step_phases.py 40 2>/dev/null > "$OUT/step_phases_$sch.txt"; done
-  timeout 300 python tools/gemm_big_bench.py 20 2>/dev/null > "$OUT/gemm_big_bench.txt"
+  bash tools/ablate_ab.sh > "$OUT/ablate.txt" 2>&1
+  { for i in 1 2; do echo "FC_MICROBATCH=1 $(FC_PROBES_LIB=1 FC_MICROBATCH=1 $B2 2>/dev/null | ms)"; done; } > "$OUT/microbatch1.txt"
 fi
 rm -f "$OUT"/*.log
 ls -la "$OUT"
