@@ -166,8 +166,16 @@ class COCOEvaluator(object):
         g = torch.as_tensor(g_features).to(dev, torch.float64).reshape(len(g_ids), -1)
         q = torch.as_tensor(q_features).to(dev, torch.float64).reshape(len(q_ids), -1)
         retrieved_items, retrieved_scores = {}, {}
+        if dev.type != "cuda":
+            raise _lib.FedcolaHipError("fedcola_amd retrieval runs on the GPU only (eval_device must be a cuda device)")
+        q, g = q.contiguous(), g.contiguous()
+        L = _lib.lib()
         for b0 in range(0, len(q_ids), batch_size):
-            sims, pred = (-(q[b0:b0 + batch_size] @ g.t())).sort(stable=True)
+            qb = q[b0:b0 + batch_size]
+            sim = torch.empty(qb.shape[0], g.shape[0], dtype=torch.float64, device=dev)
+            with torch.cuda.device(dev):        # similarities by the library's fp64 MFMA kernel (the one evaluate_recall ranks with); torch only orders them
+                _lib.check(L.fc_k_sim_f64(_lib.ptr(qb), _lib.ptr(g), _lib.ptr(sim), qb.shape[0], g.shape[0], qb.shape[1], _lib.stream_ptr()))
+            sims, pred = sim.neg_().sort(stable=True)
             for r in range(sims.shape[0]):
                 retrieved_items[q_ids[b0 + r]] = [item for item in g_ids[pred[r, :topk].cpu().numpy()]]
                 retrieved_scores[q_ids[b0 + r]] = sims[r][:topk].cpu().numpy()

@@ -155,3 +155,19 @@ def test_evaluator_on_the_hip_model():
     assert float(scores["rsum"]) == pytest.approx(exp["rsum"], rel=1e-12)
     # features are unit-norm rows of the feat_out head
     assert torch.allclose(ex["image_features"].norm(dim=-1), torch.ones(n_img, 1, dtype=torch.float64), atol=1e-5)
+
+
+def test_retrieve_topk_matches_fp64_matmul_and_stable_sort():
+    """COCOEvaluator.retrieve (eval_coco.py:243-288; not on the evaluation path): similarities from the library's fp64 MFMA kernel, the
+    reference's stable ascending sort of the negated similarities, top-k gallery ids and scores per query."""
+    from fedcola_amd.metrics.eval_coco import COCOEvaluator
+    g = torch.Generator().manual_seed(5)
+    q = torch.nn.functional.normalize(torch.randn(37, 48, generator=g, dtype=torch.float64), dim=1)
+    ga = torch.nn.functional.normalize(torch.randn(211, 48, generator=g, dtype=torch.float64), dim=1)
+    ga[17] = ga[3]                                   # an exact tie: the stable sort keeps the lower gallery index first
+    q_ids, g_ids = list(range(100, 137)), list(range(1000, 1211))
+    items, scores, _ = COCOEvaluator(eval_device="cuda").retrieve(q.numpy(), ga.numpy(), q_ids, g_ids, topk=7, batch_size=16)
+    sims, pred = (-(q @ ga.t())).sort(stable=True)
+    for r, qi in enumerate(q_ids):
+        assert items[qi] == [g_ids[j] for j in pred[r, :7].tolist()]
+        assert np.allclose(scores[qi], sims[r, :7].numpy(), rtol=0, atol=1e-12)
