@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 3   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw */
+#define FC_ABI_VERSION 4   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw;
+                              4: fc_image_u8_to_f32, fc_k_gemm_epi; fc_k_layernorm_partial_floats counts fp64 rows */
 
 enum { FC_PREC_FP32 = 0, FC_PREC_BF16 = 1 };
 enum { FC_TASK_NONE = 0, FC_TASK_CLS = 1, FC_TASK_RTV = 2 };
