@@ -117,6 +117,7 @@ def lib():
             raise FedcolaHipError(
                 f"{LIB_PATH} not found: build the HIP extension first (python -m fedcola_amd.build). "
                 "fedcola_amd has no CPU fallback.")
+        import torch  # noqa: F401  (before the library: one HIP runtime per process, the one torch ships -- see __graft_entry__.build)
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             if os.environ.get("FC_LIB_PATH") and not hasattr(l, name):
