@@ -618,31 +618,6 @@ static int tower_head_fwd(const Ctx& c, Ws& w, int i, int feat_out, float* out) 
   }
   return 0;
 }
-static int tower_forward(const Ctx& c, Ws& w, int i, const float* img, const int64_t* ids, int feat_out, float* out) {
-  const fc_model* m = c.m;
-  const fc_model_cfg& cf = m->cfg;
-  const TowerP& tp = m->tw[i];
-  TowerWs& t = w.t[i];
-  const int D = cf.dim, N = t.N, M = t.M, B = M / N, Hd = cf.mlp_hidden;
-  const float* P = c.params;
-  FC_TRY(tower_embed_fwd(c, w, i, img, ids));
-  for (int l = 0; l < cf.depth; ++l) {  // Block.forward mome.py:225-228
-    const BlockP& b = tp.blocks[l];
-    LayerWs& L = t.L[l];
-    FC_TRY(fc_layernorm_fwd(c.dt, t.x[l], P + b.n1w, P + b.n1b, L.h1, L.mean1, L.rstd1, M, D, 1e-5f, c.s));
-    { GemmEpi e; e.bias = P + b.qkv.b; FC_TRY(c.gemm_fwd(L.h1, c.W(b.qkv.w), L.qkv, M, 3 * D, D, e)); }
-    FC_TRY(c.attn_fwd(L.qkv, L.o, L.lse, B, N));
-    { GemmEpi e; e.bias = P + b.proj.b; e.res = t.x[l]; e.rowscale = dp_ptr(m, w, i, l, 0); e.rows_per_sample = N;
-      FC_TRY(c.gemm_fwd(L.o, c.W(b.proj.w), L.xmid, M, D, D, e)); }
-    FC_TRY(fc_layernorm_fwd(c.dt, L.xmid, P + b.n2w, P + b.n2b, L.h2, L.mean2, L.rstd2, M, D, 1e-5f, c.s));
-    { GemmEpi e; e.bias = P + b.fc1.b; e.preact = L.u; e.gelu_saved_grad = (c.dt == FC_BF16);   // bf16: L.u holds gelu'(u)
-      FC_TRY(c.gemm_fwd(L.h2, c.W(b.fc1.w), L.gact, M, Hd, D, e)); }
-    { GemmEpi e; e.bias = P + b.fc2.b; e.res = L.xmid; e.rowscale = dp_ptr(m, w, i, l, 1); e.rows_per_sample = N;
-      FC_TRY(c.gemm_fwd(L.gact, c.W(b.fc2.w), t.x[l + 1], M, D, Hd, e)); }
-  }
-  return tower_head_fwd(c, w, i, feat_out, out);
-}
-
 // ---- chain schedule: the towers advance layer by layer in GROUPED launches on ONE stream (LayerNorm, the four linears and their dX
 // products each take the image and the text rows in one launch: one read of a weight matrix per linear instead of three, 345 instead
 // of 150 tiles for the N = 384 GEMMs, no hardware-queue lottery); the weight gradients still run as grouped chunks on their own stream.
@@ -1371,34 +1346,7 @@ static int tower_backward(const Ctx& c, Ws& w, int i, const float* d_out, float*
       FC_TRY(linear_bwd_params(c, b.qkv, L.gdqkv, L.h1, M, grads));
       continue;
     }
-    // ---- MLP branch: x_{l+1} = xmid + s2 * (gact.W2^T + b2)
-    // drop-path: dm = dx * s2.  For every layer but the last, the LayerNorm backward that produced dx (norm1 of layer l+1) wrote the
-    // scaled copy as its second output; the last layer's dx comes from the head
-    const float* s2 = dp_ptr(m, w, i, l, 1);
-    const void* dm = dx;
-    if (s2) {
-      if (l == cf.depth - 1) FC_TRY(fc_rowscale(c.dt, dx, L.gdm, s2, N, M, D, c.s));
-      dm = L.gdm;
-    }
-    FC_TRY(linear_bwd_params(c, b.fc2, dm, L.gact, M, grads));
-    { GemmEpi e; e.gelu_in = L.u; e.gelu_saved_grad = (c.dt == FC_BF16); FC_TRY(c.gemm_dx(dm, c.W(b.fc2.w), L.gdu, M, D, Hd, e)); }                  // du = (dm.W2) * gelu'(u)
-    FC_TRY(linear_bwd_params(c, b.fc1, L.gdu, L.h2, M, grads));
-    const size_t lnp = t.ln_stride;
-    { GemmEpi e; FC_TRY(c.gemm_dx(L.gdu, c.W(b.fc1.w), t.dh, M, Hd, D, e)); }                                  // dh2
-    // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp); da = gxmid * s1 comes out of the same LayerNorm-backward pass
-    const float* s1 = dp_ptr(m, w, i, l, 0);
-    FC_TRY(c.ln_bwd(t.dh, L.xmid, L.mean2, L.rstd2, P + b.n2w, dx, L.gxmid, grads + b.n2w, grads + b.n2b, M, D, t.ln_partial + (2 * l + 1) * lnp,
-                    s1 ? L.gda : nullptr, s1, N));
-    const void* da = s1 ? (const void*)L.gda : (const void*)L.gxmid;
-    FC_TRY(linear_bwd_params(c, b.proj, da, L.o, M, grads));
-    { GemmEpi e; FC_TRY(c.gemm_dx(da, c.W(b.proj.w), t.dO, M, D, D, e)); }
-    FC_TRY(c.attn_bwd(L.qkv, L.o, t.dO, L.lse, t.delta, L.gdqkv, B, N));
-    FC_TRY(linear_bwd_params(c, b.qkv, L.gdqkv, L.h1, M, grads));
-    { GemmEpi e; FC_TRY(c.gemm_dx(L.gdqkv, c.W(b.qkv.w), t.dh, M, 3 * D, D, e)); }                             // dh1
-    const float* s2_below = l > 0 ? dp_ptr(m, w, i, l - 1, 1) : nullptr;      // the layer below wants gx[l] * s2(l-1) as its dm
-    FC_TRY(c.ln_bwd(t.dh, t.x[l], L.mean1, L.rstd1, P + b.n1w, L.gxmid, t.gx[l], grads + b.n1w, grads + b.n1b, M, D, t.ln_partial + (2 * l) * lnp,
-                    s2_below ? t.L[l - 1].gdm : nullptr, s2_below, N));
-    if (phase == PH_ALL && dw_flush_here(l)) FC_TRY(flush_dw(c));   // this chunk's weight gradients start now
+    FC_REQUIRE(false, "internal: tower_backward runs the heads, the embeddings and the weight-gradient queueing; the layers run through chain_layer_backward");
   }
   if (phase == PH_WGRAD_EMBED) {
     if (i == 0) FC_TRY(weight_grad(c, t.dtok, t.patches, B * (N - 1), D, cf.in_chans * cf.patch * cf.patch, grads + tp.pw, grads + tp.pb));
