@@ -125,7 +125,9 @@ def gemm_roofline(steps=200):
                achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
                traffic=traffic, us_per_launch=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
                algorithmic_bytes_per_launch=alg_bytes, hbm_frac=round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-               protocol="cold: every launch on another operand / output set out of a >= 1-GB ring (12 weight matrices)")
+               protocol="cold: every launch on another operand / output set out of a >= 1-GB ring (12 weight matrices)",
+               traffic_counts="bytes requested by the L2s from the fabric (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc passes over the "
+                              "same cold loop): Infinity-Cache hits are included, so this is an upper bound of the HBM bytes")
     if note:
         out["traffic_note"] = note
     # the same kernel over the whole batch's rows (how the one-chain schedule launches it): a third of the batch fills 102 tiles on 256
