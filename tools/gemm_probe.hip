@@ -1,8 +1,8 @@
 // Phase timing of the persistent LDS-DMA GEMM main loop (development aid, not product): the product's helpers are included
 // verbatim and one instrumented copy of the NT / EPI_BIAS kernel stamps s_memtime at the points of every k-step:
 //   [0] top of step  [1] after s_waitcnt vmcnt  [2] after s_barrier  [3] after the DMA issue  [4] after the MFMAs
-// build:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -I fedcola_amd/csrc tools/gemm_probe.hip fedcola_amd/build/fc_elem.hip.o \
-//         fedcola_amd/build/fc_generic.hip.o -o tools/gemm_probe      (fc_mfma.hip is #included, not linked)
+// build:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -I fedcola_amd/csrc -c tools/gemm_probe.hip -o /tmp/gemm_probe.o ; hipcc --offload-arch=gfx950 /tmp/gemm_probe.o \
+//         <every fedcola_amd/build/*.hip.o except fc_mfma.hip.o> -ldl -o tools/gemm_probe      (fc_mfma.hip is #included, not linked)
 // run:    tools/gemm_probe M N K [mode]     mode bit0: no DMA, bit1: no MFMA
 #include "../fedcola_amd/csrc/fc_mfma.hip"
 #include <algorithm>
@@ -87,10 +87,12 @@ k_probe(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bm, l
 
 int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 6304, N = argc > 2 ? atoi(argv[2]) : 384, K = argc > 3 ? atoi(argv[3]) : 1536, mode = argc > 4 ? atoi(argv[4]) : 0;
+  const int ring = argc > 5 ? atoi(argv[5]) : 1;     // > 1: every launch on another A / C out of `ring` copies (HBM-cold operand); the last launch is reported
   bf16_t *A, *W, *C;
   float* bias;
-  hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2); hipMalloc(&bias, N * 4);
-  hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(W, 0x3c, (size_t)N * K * 2); hipMemset(bias, 0, N * 4);
+  const size_t a_el = ((size_t)M * K + 1023) & ~(size_t)1023, c_el = ((size_t)M * N + 1023) & ~(size_t)1023;
+  hipMalloc(&A, a_el * 2 * ring); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&C, c_el * 2 * ring); hipMalloc(&bias, N * 4);
+  hipMemset(A, 0x3c, a_el * 2 * ring); hipMemset(W, 0x3c, (size_t)N * K * 2); hipMemset(bias, 0, N * 4);
   int tiles_n = (N + 127) / 128, tiles = ((M + 127) / 128) * tiles_n, T = (K + 63) / 64;
   int grid = std::min(tiles, 512), max_steps = ((tiles + grid - 1) / grid) * T + 2;
   long long* st;
@@ -100,16 +102,17 @@ int main(int argc, char** argv) {
   hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
-  for (int it = 0; it < 3; ++it) {
+  for (int it = 0; it < 3 + (ring > 1 ? ring : 0); ++it) {
     hipMemset(st, 0, (size_t)grid * max_steps * NSTAMP * 8);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), 65536, 0, A, (long)K, W, (long)K, C, (long)N, M, N, K, tiles_n, tiles, e, st, max_steps, mode);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), 65536, 0, A + (size_t)(it % ring) * a_el, (long)K, W, (long)K, C + (size_t)(it % ring) * c_el, (long)N, M, N, K, tiles_n, tiles, e, st,
+                       max_steps, mode);
     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
   }
   std::vector<long long> h((size_t)grid * max_steps * NSTAMP);
   hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
-  printf("M %d N %d K %d mode %d: tiles %d grid %d T %d  kernel %.1f us\n", M, N, K, mode, tiles, grid, T, ms * 1e3);
-  // s_memtime ticks at a constant 100 MHz on gfx9: report ticks (10 ns units)
+  printf("M %d N %d K %d mode %d ring %d: tiles %d grid %d T %d  kernel %.1f us\n", M, N, K, mode, ring, tiles, grid, T, ms * 1e3);
+  // s_memtime counts shader-clock cycles here (24 k-steps of ~2 000 counts in a 27-us kernel: ~2.1 GHz)
   const char* names[4] = {"wait vmcnt", "barrier", "issue DMA", "MFMA+reads"};
   for (int ph = 0; ph < 4; ++ph) {
     std::vector<long long> d;
@@ -119,7 +122,7 @@ int main(int argc, char** argv) {
         if (a > 0 && b > 0) d.push_back(b - a);
       }
     std::sort(d.begin(), d.end());
-    if (!d.empty()) printf("  %-11s median %5lld  p10 %5lld  p90 %5lld ticks (x10 ns)   n=%zu\n", names[ph], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10], d.size());
+    if (!d.empty()) printf("  %-11s median %5lld  p10 %5lld  p90 %5lld cycles   n=%zu\n", names[ph], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10], d.size());
   }
   std::vector<long long> step;
   for (int g = 0; g < grid; ++g)
@@ -128,9 +131,9 @@ int main(int argc, char** argv) {
       if (a > 0 && b > 0) step.push_back(b - a);
     }
   std::sort(step.begin(), step.end());
-  if (!step.empty()) printf("  whole k-step median %lld ticks = %.2f us\n", step[step.size() / 2], step[step.size() / 2] * 0.01);
+  if (!step.empty()) printf("  whole k-step median %lld cycles\n", step[step.size() / 2]);
   long long t0 = 1LL << 62, t1 = 0;
   for (int g = 0; g < grid; ++g) { long long a = h[(size_t)g * max_steps * NSTAMP]; if (a > 0) { t0 = std::min(t0, a); } for (int s = 0; s < max_steps; ++s) { long long b = h[((size_t)g * max_steps + s) * NSTAMP + 4]; t1 = std::max(t1, b); } }
-  printf("  first stamp -> last MFMA stamp: %.2f us\n", (t1 - t0) * 0.01);
+  printf("  first stamp -> last MFMA stamp: %lld cycles\n", t1 - t0);
   return 0;
 }
