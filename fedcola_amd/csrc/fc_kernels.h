@@ -146,6 +146,10 @@ int fc_gemm_generic(int dtA, int dtB, int dtC, const void* A, long sam, long sak
 enum { FC_GEMM_NT = 0, FC_GEMM_NN = 1, FC_GEMM_TN = 2 };
 int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm, long ldb, void* C, long ldc, int M, int N, int K,
                  const GemmEpi& epi, hipStream_t s);
+// ---- fp32 GEMMs as three bf16 MFMA products of split operands (fc_gemm_x3.hip): the GEMM of the fp32 mode; 1 = shape not covered
+int fc_gemm_x3(int kind, const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K, const GemmEpi& epi, hipStream_t s);
+// the fp32 mode's weight gradients: dW[out,in] = dY[rows,out]^T . X[rows,in] (stored) and db += column sums of dY, reduction cut into slices
+int fc_dw_x3(const float* dY, const float* X, float* dW, float* db, int rows, int out, int in, hipStream_t s);
 // the same kernel over one or two problems that share N, K and the epilogue kind (image + text tower of a layer in one launch);
 // returns 1 when not covered: the caller then launches the problems one by one
 struct GemmProb { const bf16_t* A; const bf16_t* B; void* C; long lda, ldb, ldc; int M; GemmEpi e; };

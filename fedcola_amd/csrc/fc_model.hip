@@ -512,6 +512,9 @@ struct Ctx {
     if (dt == FC_BF16) {
       int r = fc_gemm_mfma(FC_GEMM_NT, FC_BF16, (const bf16_t*)X, K, (const bf16_t*)Wt, K, Y, N, M, N, K, e, s);
       if (r <= 0) return r;
+    } else if (dt == FC_F32) {
+      int r = fc_gemm_x3(FC_GEMM_NT, (const float*)X, K, (const float*)Wt, K, (float*)Y, N, M, N, K, e, s);
+      if (r <= 0) return r;
     }
     return fc_gemm_generic(dt, dt, dt, X, K, 1, Wt, 1, K, Y, N, M, N, K, e, s);
   }
@@ -519,6 +522,9 @@ struct Ctx {
   int gemm_dx(const void* dY, const void* Wt, void* dX, int M, int N, int K, const GemmEpi& e) const {
     if (dt == FC_BF16) {
       int r = fc_gemm_mfma(FC_GEMM_NN, FC_BF16, (const bf16_t*)dY, N, (const bf16_t*)Wt, K, dX, K, M, K, N, e, s);
+      if (r <= 0) return r;
+    } else if (dt == FC_F32) {
+      int r = fc_gemm_x3(FC_GEMM_NN, (const float*)dY, N, (const float*)Wt, K, (float*)dX, K, M, K, N, e, s);
       if (r <= 0) return r;
     }
     return fc_gemm_generic(dt, dt, dt, dY, N, 1, Wt, K, 1, dX, K, M, K, N, e, s);
@@ -529,6 +535,9 @@ struct Ctx {
     e.out_zeroed = 1;  // the flat gradient buffer is zero-filled before every backward
     if (dt == FC_BF16) {
       int r = fc_gemm_mfma(FC_GEMM_TN, FC_F32, (const bf16_t*)dY, N, (const bf16_t*)X, K, dW, K, N, K, M, e, s);
+      if (r <= 0) return r;
+    } else if (dt == FC_F32) {
+      int r = fc_gemm_x3(FC_GEMM_TN, (const float*)dY, N, (const float*)X, K, dW, K, N, K, M, e, s);
       if (r <= 0) return r;
     }
     return fc_gemm_generic(dt, dt, FC_F32, dY, 1, N, X, K, 1, dW, K, N, K, M, e, s);
@@ -1298,6 +1307,10 @@ static int weight_grad(const Ctx& c, const void* dY, const void* X, int M, int o
     }
   }
   c.mark_ungraphable();      // launches that accumulate into the gradient buffer: keep such layers out of graphs
+  if (c.dt == FC_F32) {      // fp32 mode: split-operand MFMA products, the reduction over the rows cut into slices, db from the same pass
+    const int r = fc_dw_x3((const float*)dY, (const float*)X, dW, db, M, out, in, c.s);
+    if (r <= 0) return r;
+  }
   FC_TRY(c.gemm_dw(dY, X, dW, M, out, in));
   FC_TRY(fc_colsum(c.dt, dY, db, M, out, 1, c.s));
   return 0;
@@ -2168,8 +2181,12 @@ extern "C" int fc_k_gemm(int32_t impl, int32_t kind, int32_t dt_in, int32_t dt_o
   e.bias = bias;
   FC_REQUIRE(!gelu, "fc_k_gemm: gelu epilogue is exercised through fc_forward");
   if (impl == 1) {
-    FC_REQUIRE(dt_in == FC_BF16, "fc_k_gemm: MFMA path takes bf16 inputs");
     long lda = kind == FC_GEMM_TN ? M : K, ldb = kind == FC_GEMM_NT ? K : N;
+    if (dt_in == FC_F32) {          // fp32 in and out: three bf16 MFMA products of split operands (the fp32 mode's GEMM)
+      FC_REQUIRE(dt_out == FC_F32, "fc_k_gemm: the split-operand MFMA path writes fp32");
+      return fc_gemm_x3(kind, (const float*)A, lda, (const float*)Bm, ldb, (float*)C, N, M, N, K, e, s);
+    }
+    FC_REQUIRE(dt_in == FC_BF16, "fc_k_gemm: MFMA path takes bf16 or fp32 inputs");
     return fc_gemm_mfma(kind, dt_out, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, C, N, M, N, K, e, s);
   }
   long sam, sak, sbk, sbn;

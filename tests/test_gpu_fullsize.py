@@ -109,24 +109,25 @@ def test_vit_b_width_step_vs_oracle(kind, prec, otol, gtol):
         scale = max(float(go.abs().max()), 1e-7)
         rel = float((gk - go).abs().max()) / scale
         gemm_like = k.endswith(("qkv.weight", "proj.weight", "fc1.weight", "fc2.weight", "aux_weight", "head.weight")) and "embeddings" not in k
-        if gemm_like or (prec == "fp32" and go.dim() > 1):     # fp32: only true vectors (biases, LayerNorm weight / bias) are held apart
+        if gemm_like:                                   # the linears' weights: well-conditioned sums, held to gtol against the fp32 oracle
             worst = max(worst, (k, rel), key=lambda t: t[1])
-        else:
+        else:                                           # column sums: biases, LayerNorm vectors, embedding tables, cls / position rows
             worst1d = max(worst1d, (k, rel), key=lambda t: t[1])
-    print(f"{kind} {prec}: worst gradient tensor {worst}, worst 1-D {worst1d}")
+    print(f"{kind} {prec}: worst linear weight gradient {worst}, worst column-sum gradient {worst1d} (against the fp32 oracle)")
     assert worst[1] <= gtol, f"worst gradient tensor {worst}"
-    # Bias / LayerNorm vectors at B = 8 are column sums over a few hundred rows (320 text rows) that cancel to ~1e-3 of their summands.
-    # The library forms these sums in fp64 (k_colsum_f64, fp64 LayerNorm partial rows), so the summation adds nothing -- but the SUMMANDS
-    # of two fp32 implementations differ by ~1e-6 each, which after the cancellation is ~1e-4 of the result's maximum: that is the
-    # conditioning of the quantity, not an error of either side.  So the vectors are held to 1e-4 against the EXACT gradient (the same
-    # oracle run in fp64), and the fp32 oracle's own distance from it is printed beside ours; against the fp32 oracle the bound is the sum
-    # of the two (2e-4).
+    # Bias / LayerNorm vectors and the embedding tables' rows at B = 8 are column sums over a few rows to a few hundred rows (320 text rows)
+    # that cancel to ~1e-3 of their summands.  The library forms the long sums in fp64 (k_colsum_f64, fp64 LayerNorm partial rows), so the
+    # summation adds nothing -- but the SUMMANDS of two fp32 implementations differ by ~1e-6 each (the library's GEMMs are not torch's: since
+    # round 4 they are split-operand MFMA products, 5x closer to the exact product than an fp32 FMA chain, fc_gemm_x3.hip), which after the
+    # cancellation is ~1e-4 of the result's maximum: that is the conditioning of the quantity, not an error of either side.  So EVERY
+    # gradient tensor is held to 1e-4 against the EXACT gradient (the same oracle run in fp64), and the fp32 oracle's own distance from it
+    # is printed beside ours; against the fp32 oracle the bound for the column sums is the sum of the two (2e-4).
     p64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
     b64 = ("img+txt", img.double(), ids) if kind == "img+txt" else ("img", img.double(), y)
     _, _, grads_64 = O.client_step(p64, cfg, b64, dict(step=0, m={}, v={}), lr=1e-4)
     ours, theirs = ("", 0.0), ("", 0.0)
     for k, g64 in grads_64.items():
-        if g64.dim() > 1 or "cross_modal_scale" in k or "embeddings" in k and g64.dim() > 1:
+        if "cross_modal_scale" in k:
             continue
         gk, go = grads[k].double(), grads_o[k].double()
         if k.endswith("attn.qkv.bias"):
@@ -136,9 +137,9 @@ def test_vit_b_width_step_vs_oracle(kind, prec, otol, gtol):
         scale = max(float(g64.abs().max()), 1e-7)
         ours = max(ours, (k, float((gk - g64).abs().max()) / scale), key=lambda t: t[1])
         theirs = max(theirs, (k, float((go - g64).abs().max()) / scale), key=lambda t: t[1])
-    print(f"{kind} {prec}: 1-D gradients against the fp64 oracle: library {ours}, fp32 oracle {theirs}")
+    print(f"{kind} {prec}: all gradients against the fp64 oracle: library {ours}, fp32 oracle {theirs}")
     if prec == "fp32":
-        assert ours[1] <= 1e-4, f"worst 1-D gradient tensor against the exact gradient {ours}"
-        assert worst1d[1] <= 2e-4, f"worst 1-D gradient tensor against the fp32 oracle {worst1d}"
+        assert ours[1] <= 1e-4, f"worst gradient tensor against the exact gradient {ours}"
+        assert worst1d[1] <= 2e-4, f"worst column-sum gradient tensor against the fp32 oracle {worst1d}"
     else:
         assert worst1d[1] <= gtol, f"worst 1-D gradient tensor {worst1d}"

@@ -133,6 +133,9 @@ def test_evaluator_on_the_hip_model():
     n_img, caps = 12, 5
     images = det_tensor([n_img, 3, 32, 32], 11, 1.0)
     tokens = det_ids([n_img * caps, 8], 5, 97)
+    tokens[:, 0] = 1 + torch.arange(n_img * caps)      # det_ids repeats with period 12: make every caption distinct, so that no two gallery
+                                                       # entries have EQUAL similarity to a query (the tie order is pinned by its own tests above;
+                                                       # here a tie would compare numpy's dgemm rounding of duplicate columns with the kernel's)
     iids = 100 + 3 * torch.arange(n_img)
     aids = 7000 + torch.arange(n_img * caps)
     perm = (torch.arange(n_img * caps) * 7 + 3) % (n_img * caps)
