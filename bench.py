@@ -270,6 +270,42 @@ class InMemoryPairs:
         return out
 
 
+def fp32_mode_line(img, ids, B, seq, dev, steps=8):
+    """The same client step in the library's precision = 'fp32' mode (fp32 storage; the mode that holds the reference's <= 1e-4 bar on outputs and
+    gradients, tests/test_gpu_fullsize.py): its linears run on the matrix cores as six bf16 MFMA products of three-way split operands
+    (csrc/fc_gemm_x3.hip), attention and the row-wise kernels on the VALU.  A few steps, same protocol; a reported line, not the headline."""
+    import torch
+    from fedcola_amd import _lib
+    from fedcola_amd.mome import create_model
+    a32 = Args()
+    a32.precision = "fp32"
+    torch.manual_seed(1)
+    m32 = create_model("mome_small_patch16", False, args=a32, num_classes=[None, None], modalities=["img", "txt"], tasks=["rtv", "rtv"]).to(dev)
+    m32.train()
+    n = m32.flat.numel()
+    g = torch.zeros(n, device=dev); m1 = torch.zeros(n, device=dev); m2 = torch.zeros(n, device=dev)
+    lb = torch.zeros(2, device=dev)
+    m32.prepare_weights(force=True)
+    ws = m32.workspace(B, seq)
+    L, P = _lib.lib(), _lib.ptr
+    sp = _lib.stream_ptr()
+
+    def one(k):
+        _lib.check(L.fc_client_step(m32._handle.h, P(m32.flat), P(g), P(m1), P(m2), P(m32._wc_or_flat()), P(img), P(ids), None, B, seq, None,
+                                    1e-4, 0.9, 0.999, 1e-8, 0.0, k, P(lb), P(ws), ws.numel(), sp))
+    for k in range(3):
+        one(k + 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(4 + k)
+    torch.cuda.synchronize()
+    d = time.perf_counter() - t0
+    return dict(value=round(B * steps / d, 1), unit="img-txt pairs/s", ms_per_step=round(d / steps * 1e3, 2), steps=steps, dtype="fp32",
+                note="precision='fp32' (the <= 1e-4 parity mode): fp32 storage, linears as six bf16 MFMA products of three-way split operands, "
+                     "attention on the VALU")
+
+
 def extra_legs(a, args, model, step, B, seq, dev, dev_step_s):
     """h2d_inclusive: the same step with every batch coming from pinned host memory through DevicePrefetcher ("include H2D of
     the batch (pinned, overlapped)").  client_round: FedavgClient.download() + update() (E = 1, 20 steps of B from an in-memory dataset
@@ -665,6 +701,10 @@ def main():
     if rank == 0 and world == 1 and not a.no_extra_legs and not a.h2d and a.fedprox_mu == 0:
         extra = extra_legs(a, args, model, step, B, seq, dev, dt / a.steps)
 
+    fp32_line = None
+    if rank == 0 and world == 1 and not a.no_extra_legs and a.precision == "bf16" and not a.h2d and a.fedprox_mu == 0 and a.dropout == 0.0:
+        fp32_line = fp32_mode_line(img, ids, B, seq, dev)
+
     if rank == 0:
         pairs = world * cpr * B * a.steps / dt
         out = dict(metric="img-txt pairs/sec per client round (ViT-S+BERT-mini)", value=round(pairs, 1), unit="img-txt pairs/s", n_gpus=world,
@@ -701,6 +741,8 @@ def main():
         out.update(extra)
         if drop_line is not None:
             out["dropout_0p1"] = drop_line
+        if fp32_line is not None:
+            out["fp32_mode"] = fp32_line
         if not a.no_roofline:
             out["roofline"] = gemm_roofline()
         if cpu_base is not None:
