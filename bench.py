@@ -273,7 +273,8 @@ class InMemoryPairs:
 def fp32_mode_line(img, ids, B, seq, dev, steps=8):
     """The same client step in the library's precision = 'fp32' mode (fp32 storage; the mode that holds the reference's <= 1e-4 bar on outputs and
     gradients, tests/test_gpu_fullsize.py): its linears run on the matrix cores as six bf16 MFMA products of three-way split operands
-    (csrc/fc_gemm_x3.hip), attention and the row-wise kernels on the VALU.  A few steps, same protocol; a reported line, not the headline."""
+    (csrc/fc_gemm_x3.hip), attention as fp32 MFMA chains (csrc/fc_attn_f32.hip), the row-wise kernels on the VALU.  A few steps, same protocol; a
+    reported line, not the headline."""
     import torch
     from fedcola_amd import _lib
     from fedcola_amd.mome import create_model
@@ -303,7 +304,7 @@ def fp32_mode_line(img, ids, B, seq, dev, steps=8):
     d = time.perf_counter() - t0
     return dict(value=round(B * steps / d, 1), unit="img-txt pairs/s", ms_per_step=round(d / steps * 1e3, 2), steps=steps, dtype="fp32",
                 note="precision='fp32' (the <= 1e-4 parity mode): fp32 storage, linears as six bf16 MFMA products of three-way split operands, "
-                     "attention on the VALU")
+                     "attention as v_mfma_f32_16x16x4_f32 chains")
 
 
 def extra_legs(a, args, model, step, B, seq, dev, dev_step_s):

@@ -548,6 +548,9 @@ struct Ctx {
     if (dt == FC_BF16) {
       int r = fc_attn_fwd_mfma((const bf16_t*)qkv, (bf16_t*)o, lse, B, N, H, d, scale, s);
       if (r <= 0) return r;
+    } else if (dt == FC_F32) {
+      int r = fc_attn_f32_fwd((const float*)qkv, (float*)o, lse, B, N, H, d, scale, s);
+      if (r <= 0) return r;
     }
     return fc_attn_fwd_generic(dt, qkv, o, lse, B, N, H, d, scale, s);
   }
@@ -556,6 +559,9 @@ struct Ctx {
     float scale = 1.0f / sqrtf((float)d);
     if (dt == FC_BF16) {
       int r = fc_attn_bwd_mfma((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dO, lse, delta, (bf16_t*)dqkv, B, N, H, d, scale, s);
+      if (r <= 0) return r;
+    } else if (dt == FC_F32) {
+      int r = fc_attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)dO, lse, (float*)dqkv, B, N, H, d, scale, s);
       if (r <= 0) return r;
     }
     return fc_attn_bwd_generic(dt, qkv, o, dO, lse, delta, dqkv, B, N, H, d, scale, s);
@@ -2198,7 +2204,8 @@ extern "C" int fc_k_gemm(int32_t impl, int32_t kind, int32_t dt_in, int32_t dt_o
 extern "C" int fc_k_attention_fwd(int32_t impl, int32_t dt, const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, int32_t d,
                                   float scale, void* stream) {
   if (impl == 1) {
-    FC_REQUIRE(dt == FC_BF16, "MFMA attention takes bf16");
+    if (dt == FC_F32) return fc_attn_f32_fwd((const float*)qkv, (float*)o, lse, B, N, H, d, scale, (hipStream_t)stream);   // fp32 MFMA (the fp32 mode's)
+    FC_REQUIRE(dt == FC_BF16, "MFMA attention takes bf16 or fp32");
     return fc_attn_fwd_mfma((const bf16_t*)qkv, (bf16_t*)o, lse, B, N, H, d, scale, (hipStream_t)stream);
   }
   return fc_attn_fwd_generic(dt, qkv, o, lse, B, N, H, d, scale, (hipStream_t)stream);
@@ -2206,7 +2213,9 @@ extern "C" int fc_k_attention_fwd(int32_t impl, int32_t dt, const void* qkv, voi
 extern "C" int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, const void* o, const void* dout, const float* lse, float* delta,
                                   void* dqkv, int32_t B, int32_t N, int32_t H, int32_t d, float scale, void* stream) {
   if (impl == 1) {
-    FC_REQUIRE(dt == FC_BF16, "MFMA attention takes bf16");
+    if (dt == FC_F32)
+      return fc_attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)dout, lse, (float*)dqkv, B, N, H, d, scale, (hipStream_t)stream);
+    FC_REQUIRE(dt == FC_BF16, "MFMA attention takes bf16 or fp32");
     return fc_attn_bwd_mfma((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, B, N, H, d, scale,
                             (hipStream_t)stream);
   }
