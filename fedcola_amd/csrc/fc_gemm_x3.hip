@@ -9,29 +9,33 @@
 //
 //   NT: C[M,N] = A[M,K] . W[N,K]^T   (forward)      NN: C[M,N] = A[M,K] . W[K,N]   (dX)      TN: C[M,N] = A[K,M]^T . B[K,N]   (dW)
 //
-// 128 x 128 output tile, BK = 64, 256 threads = 2 x 2 waves of 64 x 64 (4 x 4 v_mfma_f32_16x16x32_bf16 accumulators, operands swapped so
-// that a lane owns 4 consecutive output columns), one workgroup per CU (96 KB of LDS): 192 MFMAs per wave between two barriers -- the
-// kernel is bound by the matrix pipe, at a sixth of the bf16 rate.  Per k-tile a thread loads 8 + 8 float4 of the two operands (the NEXT
-// tile's loads are in flight under this tile's MFMAs), splits them and writes the three images of each operand in the bf16 kernels' LDS
-// layouts (fc_mfma_dev.h: k-contiguous rows read by ds_read_b128, k-row tiles read by ds_read_b64_tr_b16), 6 x 16 KB.
+// 128 x 128 output tile, 32-k tiles, 256 threads = 2 x 2 waves of 64 x 64 (4 x 4 v_mfma_f32_16x16x32_bf16 accumulators, operands swapped so
+// that a lane owns 4 consecutive output columns), 48 KB of LDS: two or three workgroups per CU, so that one's split / store phase runs under
+// another's 96 MFMAs per wave, and the 297-tile launches of the N = 384 linears fit the chip in one round.  Per k-tile a thread loads 4 + 4
+// float4 of the two operands (the NEXT tile's loads are in flight under this tile's MFMAs), splits them and writes the three images of each
+// operand, 6 x 8 KB: k-contiguous operands as [128 rows][32 k] (64-byte rows, 16-byte chunk g of row r at g ^ ((r >> 3) & 1) << 1: conflict-
+// free ds_read_b128 fragments), k-row operands as the first 32 rows of the bf16 kernels' k-row layout (fc_mfma_dev.h, ds_read_b64_tr_b16).
 #include <map>
 #include <mutex>
 
 #include "fc_kernels.h"
 #include "fc_mfma_dev.h"
 
-struct X3Regs { float4 v[8]; };
+#define XK 32            // k per tile
+#define XIMG 8192        // bytes of one bf16 image of an operand tile
+struct X3Regs { float4 v[4]; };
+__device__ __forceinline__ int kc32_off(int row, int c) { return row * 64 + ((c ^ (((row >> 3) & 1) << 1)) << 4); }
 
-// One operand tile: KC = P[row][k] (k contiguous; thread owns the 8-k chunk c = tid & 7 of rows (tid >> 3) + 32 p), KR = P[k][col] (thread owns the
+// One operand tile: KC = P[row][k] (k contiguous; thread owns the 8-k chunk c = tid & 3 of rows (tid >> 2) + 64 p), KR = P[k][col] (thread owns the
 // 8-column chunk c = tid & 15 of k rows (tid >> 4) + 16 p).  Out-of-range rows / columns / k read as zero.
 template <int MODE>
 __device__ __forceinline__ void x3_load(X3Regs& R, const float* __restrict__ P, long ld, int r0, int nrows, int k0, int K, int tid) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < 2; ++p) {
     bool ok;
     const float* src;
     if (MODE == KC) {
-      const int row = r0 + (tid >> 3) + 32 * p, k = k0 + (tid & 7) * 8;
+      const int row = r0 + (tid >> 2) + 64 * p, k = k0 + (tid & 3) * 8;
       ok = row < nrows && k < K;
       src = P + (size_t)(ok ? row : 0) * ld + (ok ? k : 0);
     } else {
@@ -53,19 +57,25 @@ __device__ __forceinline__ void x3_split(float a, float b, unsigned& hi, unsigne
   lo = f2bf2(ra - bf2f(ma), rb - bf2f(mb));                  // exact differences again
 }
 template <int MODE>
-__device__ __forceinline__ void x3_store(const X3Regs& R, char* img, int tid) {   // img: hi | mid | lo images, 16 KB apart
+__device__ __forceinline__ void x3_store(const X3Regs& R, char* img, int tid) {   // img: hi | mid | lo images, XIMG apart
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < 2; ++p) {
     uint4 h, m, l;
     x3_split(R.v[2 * p].x, R.v[2 * p].y, h.x, m.x, l.x);
     x3_split(R.v[2 * p].z, R.v[2 * p].w, h.y, m.y, l.y);
     x3_split(R.v[2 * p + 1].x, R.v[2 * p + 1].y, h.z, m.z, l.z);
     x3_split(R.v[2 * p + 1].z, R.v[2 * p + 1].w, h.w, m.w, l.w);
-    const int off = MODE == KC ? kc_off((tid >> 3) + 32 * p, tid & 7) : kr_off((tid >> 4) + 16 * p, tid & 15);
+    const int off = MODE == KC ? kc32_off((tid >> 2) + 64 * p, tid & 3) : kr_off((tid >> 4) + 16 * p, tid & 15);
     *(uint4*)(img + off) = h;
-    *(uint4*)(img + 16384 + off) = m;
-    *(uint4*)(img + 32768 + off) = l;
+    *(uint4*)(img + XIMG + off) = m;
+    *(uint4*)(img + 2 * XIMG + off) = l;
   }
+}
+// fragment of the 16-wide block at rb: lane (r = lane & 15, g = lane >> 4) gets k = 8 g .. 8 g + 7 of row (column) rb + r
+template <int MODE>
+__device__ __forceinline__ bf16x8 x3_frag(const char* img, int rb, int lane) {
+  if (MODE == KC) return *(const bf16x8*)(img + kc32_off(rb + (lane & 15), lane >> 4));
+  return frag_read<KR>(img, rb, 0, lane);
 }
 
 // the epilogue of one lane's 4 consecutive columns of row m (fp32 in, fp32 out; erf-GELU as the reference's nn.GELU)
@@ -112,61 +122,75 @@ __device__ __forceinline__ void x3_epi4(float* C, long ldc, int m, int n, f32x4 
   *(float4*)(C + o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// one 64-k tile of the six-product sum from the LDS images into the running fp32 accumulators
+// one 32-k tile of the six-product sum from the LDS images into the running fp32 accumulators.
+// The matrix pipe's fp32 accumulate rounds toward -inf (measured: a systematic error of -6e-11 |result| per k element when every product of a
+// 12 608-long reduction lands in one accumulator -- harmless per element, but the column sums downstream add it 12 608 times).  So the six
+// products of a tile go into a fresh accumulator that joins the running sum by a round-to-nearest VALU add, and every second tile runs with
+// the A fragments negated and is subtracted: a rounding toward -inf becomes one toward +inf there, the two directions cancel on average.
 template <int AMODE, int BMODE>
-__device__ __forceinline__ void x3_compute(const char* ai, const char* bi, f32x4 (&acc)[4][4], int wm, int wn, int lane) {
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 fa[3][4], fb[3][4];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[c][i] = frag_read<AMODE>(ai + c * 16384, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[c][j] = frag_read<BMODE>(bi + c * 16384, wn * 64 + j * 16, ks, lane);
-      if (AMODE == KR) frag_fence(fa[c]);
-      if (BMODE == KR) frag_fence(fb[c]);
-    }
-    // (and in every second half-step with the A fragments negated and the partial subtracted: a rounding toward -inf becomes one toward
-    // +inf there, the two directions cancel on average)
-    if (ks & 1) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          uint4 u = *(uint4*)&fa[c][i];
-          u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
-          fa[c][i] = *(bf16x8*)&u;
-        }
-    }
-    // The matrix pipe's fp32 accumulate truncates (measured: a systematic error of -6e-11 |result| per k element when every product of a
-    // 12 608-long reduction lands in one accumulator -- harmless per element, but the column sums downstream add it 12 608 times).  So the
-    // six products of a 32-k half-step go into a fresh accumulator and join the running sum by a round-to-nearest VALU add.
-    f32x4 part[4][4];
-#define X3_MFMA0(ca, cb)                                                                                                 \
+__device__ __forceinline__ void x3_compute(const char* ai, const char* bi, f32x4 (&acc)[4][4], int wm, int wn, int lane, bool odd) {
+  const unsigned flip = odd ? 0x80008000u : 0u;
+  f32x4 part[4][4];
+#define X3_LOAD_A(f, c)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) f[i] = x3_frag<AMODE>(ai + (c) * XIMG, wm * 64 + i * 16, lane);          \
+  if (AMODE == KR) frag_fence(f);                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                        \
+    uint4 u = *(uint4*)&f[i];                                                                                            \
+    u.x ^= flip; u.y ^= flip; u.z ^= flip; u.w ^= flip;                                                                  \
+    f[i] = *(bf16x8*)&u;                                                                                                 \
+  }
+#define X3_LOAD_B(f, c)                                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) f[j] = x3_frag<BMODE>(bi + (c) * XIMG, wn * 64 + j * 16, lane);          \
+  if (BMODE == KR) frag_fence(f);
+#define X3_MFMA0(fa_, fb_)                                                                                               \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                            \
-  part[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cb][j], fa[ca][i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
-#define X3_MFMA(ca, cb)                                                                                                  \
+  part[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j], fa_[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
+#define X3_MFMA(fa_, fb_)                                                                                                \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                            \
-  part[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cb][j], fa[ca][i], part[i][j], 0, 0, 0)
-    X3_MFMA0(2, 0); X3_MFMA(0, 2); X3_MFMA(1, 1);         // 2^-16 terms first, the leading product last
-    X3_MFMA(1, 0); X3_MFMA(0, 1);
-    X3_MFMA(0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (ks & 1) ? acc[i][j] - part[i][j] : acc[i][j] + part[i][j];
+  part[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j], fa_[i], part[i][j], 0, 0, 0)
+  // the 2^-16 terms first, the leading product last; at most four fragment sets (A hi, B hi, A mid, B mid) are live at a time
+  bf16x8 ah[4], bh[4];
+  X3_LOAD_A(ah, 0);
+  {
+    bf16x8 bl[4];
+    X3_LOAD_B(bl, 2);
+    X3_MFMA0(ah, bl);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  X3_LOAD_B(bh, 0);
+  {
+    bf16x8 al[4];
+    X3_LOAD_A(al, 2);
+    X3_MFMA(al, bh);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    bf16x8 am[4], bm[4];
+    X3_LOAD_A(am, 1);
+    X3_LOAD_B(bm, 1);
+    X3_MFMA(am, bm);
+    X3_MFMA(am, bh);
+    X3_MFMA(ah, bm);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  X3_MFMA(ah, bh);
+#undef X3_LOAD_A
+#undef X3_LOAD_B
 #undef X3_MFMA0
 #undef X3_MFMA
-  }
+  const float sgn = odd ? -1.0f : 1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] += sgn * part[i][j];
 }
 
 template <int AMODE, int BMODE>
-__global__ void __launch_bounds__(256, 1) k_gemm_x3(const float* __restrict__ A, long lda, const float* __restrict__ Bm, long ldb, float* __restrict__ C, long ldc,
+__global__ void __launch_bounds__(256, 2) k_gemm_x3(const float* __restrict__ A, long lda, const float* __restrict__ Bm, long ldb, float* __restrict__ C, long ldc,
                                                     int M, int N, int K, int tiles_n, GemmEpi e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // A: hi | mid | lo, then B: hi | mid | lo, 16 KB each
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // A: hi | mid | lo, then B: hi | mid | lo, 8 KB each
   char* ai = smem;
-  char* bi = smem + 49152;
+  char* bi = smem + 3 * XIMG;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -176,7 +200,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_x3(const float* __restrict__ A,
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int T = (K + BK - 1) / BK;
+  const int T = (K + XK - 1) / XK;
   X3Regs ra, rb;
   x3_load<AMODE>(ra, A, lda, m0, M, 0, K, tid);
   x3_load<BMODE>(rb, Bm, ldb, n0, N, 0, K, tid);
@@ -185,10 +209,10 @@ __global__ void __launch_bounds__(256, 1) k_gemm_x3(const float* __restrict__ A,
     x3_store<BMODE>(rb, bi, tid);
     lds_barrier();
     if (kt + 1 < T) {                                      // the next tile's loads fly under this tile's MFMAs
-      x3_load<AMODE>(ra, A, lda, m0, M, (kt + 1) * BK, K, tid);
-      x3_load<BMODE>(rb, Bm, ldb, n0, N, (kt + 1) * BK, K, tid);
+      x3_load<AMODE>(ra, A, lda, m0, M, (kt + 1) * XK, K, tid);
+      x3_load<BMODE>(rb, Bm, ldb, n0, N, (kt + 1) * XK, K, tid);
     }
-    x3_compute<AMODE, BMODE>(ai, bi, acc, wm, wn, lane);
+    x3_compute<AMODE, BMODE>(ai, bi, acc, wm, wn, lane, kt & 1);
     lds_barrier();                                         // fragment reads done before the images are overwritten
   }
   const int g = lane >> 4, cl = lane & 15;
@@ -204,50 +228,77 @@ __global__ void __launch_bounds__(256, 1) k_gemm_x3(const float* __restrict__ A,
   }
 }
 
+// out[c][r] = in[r][c] for an fp32 matrix of `rows` x `cols` (row stride ld): 32 x 32 tiles through LDS
+__global__ void __launch_bounds__(256) k_x3_transpose(const float* __restrict__ in, long ld, float* __restrict__ out, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    t[ty + 8 * i][tx] = (r < rows && c < cols) ? in[(size_t)r * ld + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < cols && r < rows) out[(size_t)c * rows + r] = t[tx][ty + 8 * i];
+  }
+}
+
 // ======================================================================== weight gradients of the fp32 mode
 // dW[out, in] = dY[rows, out]^T . X[rows, in] and db[out] = column sums of dY: the output has 9 - 72 tiles and the reduction runs over all
 // the rows of the batch (12 608), so the reduction is cut into S slices (tiles x S ~ two workgroups per CU); slice s writes its raw partial
-// tile to part[s] and -- the workgroups of column tile 0 -- the fp64 column sums of its rows of dY (taken from the fp32 staging registers,
-// before the split) to colp[s]; k_dw_x3_reduce then adds the slices in a fixed order in fp64.  No atomics: the same bits every run.
-__global__ void __launch_bounds__(256, 1) k_dw_x3(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part, double* __restrict__ colp,
-                                                  int rows, int out, int in, int tiles_n, int tiles, int kt_per) {
+// tile to part[s], k_colsum_slices the fp64 column sums of a slice of dY's rows to colp[s] (in the product kernel they cost 48 spilled
+// registers), and k_dw_x3_reduce adds the slices in a fixed order in fp64.  No atomics: the same bits every run.
+__global__ void __launch_bounds__(256) k_colsum_slices(const float* __restrict__ dY, double* __restrict__ colp, int rows, int out, int rows_per) {
+  __shared__ double red[16][64];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, col = blockIdx.x * 64 + tx * 4, sl = blockIdx.y;
+  const int r_end = (sl + 1) * rows_per < rows ? (sl + 1) * rows_per : rows;
+  double a = 0., b = 0., c = 0., d = 0.;
+  if (col < out)
+    for (int r = sl * rows_per + ty; r < r_end; r += 16) {
+      const float4 v = *(const float4*)(dY + (size_t)r * out + col);
+      a += v.x; b += v.y; c += v.z; d += v.w;
+    }
+  red[ty][tx * 4] = a; red[ty][tx * 4 + 1] = b; red[ty][tx * 4 + 2] = c; red[ty][tx * 4 + 3] = d;
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < out) {
+    double v = 0.;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v += red[r][threadIdx.x];
+    colp[(size_t)sl * out + blockIdx.x * 64 + threadIdx.x] = v;
+  }
+}
+__global__ void __launch_bounds__(256, 2) k_dw_x3(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part, int rows, int out, int in,
+                                                  int tiles_n, int tiles, int kt_per) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ai = smem;
-  char* bi = smem + 49152;
+  char* bi = smem + 3 * XIMG;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int sl = blockIdx.x / tiles, t = blockIdx.x % tiles;
   const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-  const bool do_col = colp != nullptr && (t % tiles_n) == 0;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  double cs[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
-  const int T = (rows + BK - 1) / BK;
+  const int T = (rows + XK - 1) / XK;
   const int k_beg = sl * kt_per, k_end = (k_beg + kt_per < T) ? k_beg + kt_per : T;
   X3Regs ra, rb;
   if (k_beg < k_end) {
-    x3_load<KR>(ra, dY, out, m0, out, k_beg * BK, rows, tid);
-    x3_load<KR>(rb, X, in, n0, in, k_beg * BK, rows, tid);
+    x3_load<KR>(ra, dY, out, m0, out, k_beg * XK, rows, tid);
+    x3_load<KR>(rb, X, in, n0, in, k_beg * XK, rows, tid);
   }
   for (int kt = k_beg; kt < k_end; ++kt) {
-    if (do_col) {                                          // this thread's 8 columns x 4 k rows of the tile
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        cs[0] += ra.v[2 * p].x; cs[1] += ra.v[2 * p].y; cs[2] += ra.v[2 * p].z; cs[3] += ra.v[2 * p].w;
-        cs[4] += ra.v[2 * p + 1].x; cs[5] += ra.v[2 * p + 1].y; cs[6] += ra.v[2 * p + 1].z; cs[7] += ra.v[2 * p + 1].w;
-      }
-    }
     x3_store<KR>(ra, ai, tid);
     x3_store<KR>(rb, bi, tid);
     lds_barrier();
     if (kt + 1 < k_end) {
-      x3_load<KR>(ra, dY, out, m0, out, (kt + 1) * BK, rows, tid);
-      x3_load<KR>(rb, X, in, n0, in, (kt + 1) * BK, rows, tid);
+      x3_load<KR>(ra, dY, out, m0, out, (kt + 1) * XK, rows, tid);
+      x3_load<KR>(rb, X, in, n0, in, (kt + 1) * XK, rows, tid);
     }
-    x3_compute<KR, KR>(ai, bi, acc, wm, wn, lane);
+    x3_compute<KR, KR>(ai, bi, acc, wm, wn, lane, kt & 1);
     lds_barrier();
   }
   const int g = lane >> 4, cl = lane & 15;
@@ -260,18 +311,6 @@ __global__ void __launch_bounds__(256, 1) k_dw_x3(const float* __restrict__ dY, 
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * g;
       if (n < in) *(float4*)(P + (size_t)m * in + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    }
-  }
-  if (do_col) {                                            // 16 threads (tid >> 4) share a column chunk (tid & 15): add them through LDS
-    double* red = (double*)smem;                           // [16 k-groups][128 columns]
-#pragma unroll
-    for (int x = 0; x < 8; ++x) red[(tid >> 4) * 128 + (tid & 15) * 8 + x] = cs[x];
-    __syncthreads();
-    if (tid < 128) {
-      double v = 0.;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v += red[r * 128 + tid];
-      if (m0 + tid < out) colp[(size_t)sl * out + m0 + tid] = v;
     }
   }
 }
@@ -319,7 +358,7 @@ int fc_dw_x3(const float* dY, const float* X, float* dW, float* db, int rows, in
   if (!on) return 1;
   if (rows <= 0 || out <= 0 || in <= 0) return 1;
   if ((out & 7) || (in & 7) || ((uintptr_t)dY & 15) || ((uintptr_t)X & 15) || ((uintptr_t)dW & 15)) return 1;
-  const int tiles_n = fc_cdiv(in, BN), tiles = fc_cdiv(out, BM) * tiles_n, T = fc_cdiv(rows, BK);
+  const int tiles_n = fc_cdiv(in, BN), tiles = fc_cdiv(out, BM) * tiles_n, T = fc_cdiv(rows, XK);
   int S = 512 / tiles;
   if (S > 32) S = 32;
   if (S > T) S = T;
@@ -333,11 +372,15 @@ int fc_dw_x3(const float* dY, const float* X, float* dW, float* db, int rows, in
   double* colp = db ? (double*)(ws + pbytes) : nullptr;
   static bool attr_done = false;
   if (!attr_done) {
-    FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * XIMG));
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_dw_x3, dim3(tiles * S), dim3(256), 98304, s, dY, X, part, colp, rows, out, in, tiles_n, tiles, kt_per);
+  hipLaunchKernelGGL(k_dw_x3, dim3(tiles * S), dim3(256), 6 * XIMG, s, dY, X, part, rows, out, in, tiles_n, tiles, kt_per);
   FC_LAUNCH_CHECK();
+  if (colp) {
+    hipLaunchKernelGGL(k_colsum_slices, dim3(fc_cdiv(out, 64), S), dim3(256), 0, s, dY, colp, rows, out, fc_cdiv(rows, S));
+    FC_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(k_dw_x3_reduce, dim3(fc_cdiv((long)n / 4, 256)), dim3(256), 0, s, part, colp, dW, db, (long)n, out, S);
   FC_LAUNCH_CHECK();
   return 0;
@@ -356,7 +399,7 @@ int fc_gemm_x3(int kind, const float* A, long lda, const float* Bm, long ldb, fl
   if ((e.bias && !x3_al16(e.bias)) || (e.res && !x3_al16(e.res)) || (e.preact && !x3_al16(e.preact)) || (e.gelu_in && !x3_al16(e.gelu_in)) || (e.pos && !x3_al16(e.pos)))
     return 1;
   const int tiles_n = fc_cdiv(N, BN), tiles = fc_cdiv(M, BM) * tiles_n;
-  const int lds = 98304;
+  const int lds = 6 * XIMG;
 #define X3_GO(AM, BMo)                                                                                                  \
   do {                                                                                                                  \
     auto kfn = k_gemm_x3<AM, BMo>;                                                                                      \
@@ -368,8 +411,24 @@ int fc_gemm_x3(int kind, const float* A, long lda, const float* Bm, long ldb, fl
     hipLaunchKernelGGL(kfn, dim3(tiles), dim3(256), lds, s, A, lda, Bm, ldb, C, ldc, M, N, K, tiles_n, e);              \
   } while (0)
   if (kind == FC_GEMM_NT) X3_GO(KC, KC);
-  else if (kind == FC_GEMM_NN) X3_GO(KC, KR);
-  else if (kind == FC_GEMM_TN) X3_GO(KR, KR);
+  else if (kind == FC_GEMM_NN) {
+    // dX = dY . W with W[K][N] row-major: its tile would be a k-row image (transposing LDS reads, two per fragment, and 20 more live registers:
+    // 364 against 536 TFLOP/s of MFMA rate on 12 608 x 384 x 1536).  W is small (<= 2.4 MB): transpose it into the stream's scratch and run the
+    // k-contiguous form.
+    static const int tr = fc_knob("FC_X3_NN_TRANSPOSE", 1);
+    if (tr) {
+      char* ws = nullptr;
+      FC_TRY(x3_scratch(s, (size_t)N * K * sizeof(float), &ws));
+      float* WT = (float*)ws;
+      hipLaunchKernelGGL(k_x3_transpose, dim3(fc_cdiv(N, 32), fc_cdiv(K, 32)), dim3(256), 0, s, Bm, ldb, WT, K, N);
+      FC_LAUNCH_CHECK();
+      Bm = WT;
+      ldb = K;
+      X3_GO(KC, KC);
+    } else {
+      X3_GO(KC, KR);
+    }
+  } else if (kind == FC_GEMM_TN) X3_GO(KR, KR);
   else return 1;
 #undef X3_GO
   FC_LAUNCH_CHECK();
