@@ -88,3 +88,21 @@ def test_bench_gpus_flag_without_enough_devices_fails_loudly(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert p.returncode != 0 and "only" in p.stderr
+
+
+def test_bench_single_gpu_line_carries_the_contract_and_the_reported_legs():
+    """The N = 1 line: the driver's contract keys, the dropout line, the client-round / sustained legs and the fp32-mode leg (the <= 1e-4 parity mode on
+    the matrix cores: slower than the bf16 headline, faster than 100 ms -- it was 200 ms on the VALU)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-roofline"]
+    p = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 1 and rec["steps"] == 8 and rec["dtype"] == "bf16" and rec["vs_baseline"] is None and "workload" in rec["config"]
+    assert abs(rec["value"] - 64 / (rec["ms_per_step"] * 1e-3)) <= 0.01 * rec["value"]
+    assert rec["dropout_0p1"]["ms_per_step"] > 0 and rec["sustained"]["seconds"] >= 5
+    f32 = rec["fp32_mode"]
+    assert f32["dtype"] == "fp32" and rec["ms_per_step"] < f32["ms_per_step"] < 100.0

@@ -69,6 +69,11 @@ if [ -f fedcola_amd/libfedcola_hip_probes.so ]; then
   bash tools/ablate_ab.sh > "$OUT/ablate.txt" 2>&1
   { for i in 1 2; do echo "FC_MICROBATCH=1 $(FC_PROBES_LIB=1 FC_MICROBATCH=1 $B2 2>/dev/null | ms)"; done; } > "$OUT/microbatch1.txt"
 fi
+# 7. round 4: the fp32 mode on the matrix cores (split-operand GEMMs, fp32 MFMA attention)
+timeout 200 python tools/x3_accuracy.py 2>/dev/null | grep kind > "$OUT/x3_accuracy_now.txt"
+timeout 200 python tools/x3_bench.py 2>/dev/null | grep -E "gemm|attention" > "$OUT/x3_bench.txt"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr32 -o g -- python3 bench.py --precision fp32 --no-cpu-baseline --no-roofline --no-dropout-line --no-extra-legs --steps 5 --warmup 2 > "$OUT/tr32.log" 2>&1
+python tools/stats_top.py /tmp/tr32 7 > "$OUT/fp32_step_kernels.txt" 2>&1
 rm -f "$OUT"/*.log
 ls -la "$OUT"
 cat "$OUT/bench_line.json"
