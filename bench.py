@@ -51,14 +51,16 @@ def make_batch(B, seq, vocab, seed, device):
     return img.to(device), ids.to(device)
 
 
+ROOF_SOURCES = ("fc_common.h", "fc_kernels.h", "fc_mfma.hip", "fc_mfma_dev.h")     # what the roofline kernel (k_gemm_mfma) is compiled from
+
+
 def kernel_source_stamp():
-    """sha256 over the kernel sources: the PMC traffic figure in profiles/ is only valid for the sources it was measured on."""
+    """sha256 over the roofline kernel's sources: the PMC traffic figure in profiles/ is only valid for the sources it was measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "fedcola_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ROOF_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -2223,6 +2223,12 @@ extern "C" int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, con
 }
 // one weight-gradient problem through the grouped kernels (wide = 1: 128x384 tiles, needs in % 384 == 0): tests / tools
 extern "C" int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, float* db, int32_t rows, int32_t out, int32_t in, void* stream) {
+  if (wide == 3) {      // the fp32 mode's form: fp32 operands, split-operand MFMA products, sliced reduction; db ACCUMULATES (as in the model)
+    const int r = fc_dw_x3((const float*)dY, (const float*)X, dW, db, rows, out, in, (hipStream_t)stream);
+    FC_REQUIRE(r <= 0, "fc_k_dw: fp32 operands must be 16-B aligned with out, in multiples of 8");
+    FC_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return r;
+  }
   FcTnProblem p{(const bf16_t*)dY, (const bf16_t*)X, dW, db, out, in, in, out, in, rows, 0, 0};   // lda, ldb, ldc, M, N, K
   FC_REQUIRE(fc_gemm_tn_grouped_supported(p), "fc_k_dw: operands must be 16-B aligned with out, in multiples of 8");
   int tiles;

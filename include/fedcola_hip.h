@@ -270,7 +270,8 @@ int fc_k_attention_fwd(int32_t impl, int32_t dt, const void* qkv, void* o, float
 int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, const void* o, const void* dout, const float* lse,
                        float* delta, void* dqkv, int32_t B, int32_t N, int32_t H, int32_t d, float scale, void* stream);
 /* one weight-gradient problem of the backward through the grouped kernels: dW[out,in] (fp32) = dY[rows,out]^T . X[rows,in] (bf16
- * operands), db[out] = column sums of dY (may be NULL).  wide: 0 = 128x128 tiles; 1 / 2 = 128x384 tiles (need in % 384 == 0), 8 waves / 8 consumer + 2 LDS-DMA loader waves.
+ * operands), db[out] = column sums of dY (may be NULL).  wide: 0 = 128x128 tiles; 1 / 2 = 128x384 tiles (need in % 384 == 0), 8 waves / 8 consumer + 2 LDS-DMA loader waves;
+ * 3 = the fp32 mode's form: dY, X are FP32, products by split-operand MFMAs, the row reduction cut into slices added in fp64, and db is ADDED TO.
  * Test entry point: allocates its one-entry problem table and synchronises the stream. */
 int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, float* db, int32_t rows, int32_t out, int32_t in, void* stream);
 int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,

@@ -132,6 +132,29 @@ def test_grouped_weight_gradient_kernels(wide, rows, out, inn):
     assert (db.double().cpu() - refb).abs().max().item() <= tol * max(1.0, refb.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,out,inn", [(197 * 4, 384, 384), (777, 200, 768), (64 * 5 + 17, 1536, 384), (12608, 384, 1152), (12608, 1536, 384), (30, 8, 8)])
+def test_fp32_mode_weight_gradient_kernel(rows, out, inn):
+    """The fp32 mode's dW = dY^T . X and db += colsum(dY) (fc_gemm_x3.hip: three-way split operands, six bf16 MFMA products, the row
+    reduction cut into slices whose partial tiles are added in fp64): ragged row counts, out / in not multiples of 128, the model's full reduction
+    length -- held an order of magnitude tighter than an fp32 FMA chain would be (2e-6 of the largest element at 12 608 rows), the bias
+    gradient accumulating onto what the buffer held, and the same bits on a second run (no atomics)."""
+    g = torch.Generator().manual_seed(rows + 3 * out + 5 * inn)
+    dY = torch.randn(rows, out, generator=g) * 0.5
+    X = torch.randn(rows, inn, generator=g) * 0.5 + 0.1
+    db0 = torch.randn(out, generator=g)
+    res = []
+    for _ in range(2):
+        dW = torch.full((out, inn), float("nan"), device="cuda")
+        db = dev(db0.clone())
+        L().check(L().lib().fc_k_dw(3, P(dev(dY)), P(dev(X)), P(dW), P(db), rows, out, inn, S()))
+        res.append((dW.cpu(), db.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    ref = dY.double().t() @ X.double()
+    assert (res[0][0].double() - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    refb = db0.double() + dY.double().sum(0)
+    assert (res[0][1].double() - refb).abs().max().item() <= 2e-6 * max(1.0, refb.abs().max().item())
+
+
 def attn_ref(qkv, B, N, H, d):
     q5 = qkv.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4).double()
     q, k, v = q5[0] * d ** -0.5, q5[1], q5[2]

@@ -21,7 +21,7 @@ for d in dirs:
             v = v[3:] if len(v) > 6 else v            # skip warm-up launches
             vals[k] = sum(v) / len(v)
 rec = dict(kernel=rec_name + " (NN dX GEMM) at the roofline shape of bench.py", shape=[bench.ROOF_KIND, bench.ROOF_M, bench.ROOF_N, bench.ROOF_K],
-           source_stamp=bench.kernel_source_stamp())
+           source_stamp=bench.kernel_source_stamp(), source_stamp_covers=list(bench.ROOF_SOURCES))
 for k, v in vals.items():
     rec[k + "_per_launch"] = v
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
