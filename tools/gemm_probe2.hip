@@ -26,7 +26,7 @@ __global__ void k_pack_b(const bf16_t* __restrict__ W, uint4* __restrict__ Bp, i
   }
 }
 
-template <int DUMMY>
+template <int DA>
 __global__ void __launch_bounds__(256, 2) k_probe2(const bf16_t* __restrict__ A, long lda, const uint4* __restrict__ Bp, bf16_t* __restrict__ C, long ldc, int M, int N,
                                                    int K, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // NS x 16 KB of A
@@ -55,15 +55,19 @@ __global__ void __launch_bounds__(256, 2) k_probe2(const bf16_t* __restrict__ A,
                  "buffer_load_dwordx4 %2, %4, %5, %6 offen offset:2048\n\tbuffer_load_dwordx4 %3, %4, %5, %6 offen offset:3072" \
                  : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(bl), "s"(rb), "s"(so) : "memory");       \
   } while (0)
-#define WAIT_B(bcur) asm volatile("s_waitcnt vmcnt(16)" : "+v"(bcur[0]), "+v"(bcur[1]), "+v"(bcur[2]), "+v"(bcur[3])::"memory")
-#define ISSUE_A(kt) stage_glds<KC>(oa, smem + ((kt) % NS) * 16384, (kt) * BK, K, wave, lane)   /* past K: the descriptor zero-fills */
+#define WAIT_B(bcur)                                                                                                                   \
+  do {                                                                                                                                 \
+    if (DA == 3) asm volatile("s_waitcnt vmcnt(16)" : "+v"(bcur[0]), "+v"(bcur[1]), "+v"(bcur[2]), "+v"(bcur[3])::"memory");            \
+    else asm volatile("s_waitcnt vmcnt(4)" : "+v"(bcur[0]), "+v"(bcur[1]), "+v"(bcur[2]), "+v"(bcur[3])::"memory");                     \
+  } while (0)
+#define ISSUE_A(kt) stage_glds<KC>(oa, smem + ((kt) % (DA + 1)) * 16384, (kt) * BK, K, wave, lane)   /* past K: the descriptor zero-fills */
 #define STEP(bcur, kt)                                                                                                      \
   do {                                                                                                                      \
     WAIT_B(bcur);                                       /* everything but the two younger k-tiles (4 DMA + 4 loads each) */  \
     __builtin_amdgcn_s_barrier();                                                                                           \
     asm volatile("" ::: "memory");                                                                                          \
-    ISSUE_A((kt) + 3);                                                                                                      \
-    const char* la = smem + ((kt) % NS) * 16384;                                                                            \
+    ISSUE_A((kt) + DA);                                                                                                     \
+    const char* la = smem + ((kt) % (DA + 1)) * 16384;                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                      \
       bf16x8 af[8];                                                                                                         \
       _Pragma("unroll") for (int i = 0; i < 8; ++i) af[i] = frag_read<KC>(la, i * 16, ks, lane);                            \
@@ -72,9 +76,15 @@ __global__ void __launch_bounds__(256, 2) k_probe2(const bf16_t* __restrict__ A,
     }                                                                                                                       \
     LOAD_B(bcur, (kt) + 3);                                                                                                 \
   } while (0)
-  ISSUE_A(0); LOAD_B(b0, 0);
-  ISSUE_A(1); LOAD_B(b1, 1);
-  ISSUE_A(2); LOAD_B(b2, 2);
+  if (DA == 3) {
+    ISSUE_A(0); LOAD_B(b0, 0);
+    ISSUE_A(1); LOAD_B(b1, 1);
+    ISSUE_A(2); LOAD_B(b2, 2);
+  } else {           // B three k-tiles ahead in registers, A one k-tile ahead in a two-stage ring: order = B0 B1 A0 B2, then per step A(k+1) ... B(k+3)
+    LOAD_B(b0, 0); LOAD_B(b1, 1);
+    ISSUE_A(0);
+    LOAD_B(b2, 2);
+  }
   for (int t = 0; t < T; t += 3) {            // T is a multiple of 3 for the model's K (384, 1152, 1536); a tail would run on zero tiles
     STEP(b0, t);
     if (t + 1 < T) STEP(b1, t + 1);
@@ -107,7 +117,7 @@ int main(int argc, char** argv) {
   for (int r = 0; r < ring; ++r) hipMemcpy(A + (size_t)r * a_el, h.data(), a_el * 2, hipMemcpyHostToDevice);
   hipMemcpy(W, h.data() + 12345, (size_t)N * K * 2, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(k_pack_b, dim3(512), dim3(256), 0, 0, W, Bp, N, K, tiles_n);
-  hipFuncSetAttribute((const void*)k_probe2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * 16384);
+  hipFuncSetAttribute((const void*)k_probe2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * 16384);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   GemmEpi e{}; e.alpha = 1.f;
   float ms_p = 0, ms_q = 0;
@@ -117,11 +127,19 @@ int main(int argc, char** argv) {
     hipEventRecord(e0);
     for (int it = 0; it < reps; ++it) fc_gemm_mfma(FC_GEMM_NT, FC_BF16, A + (size_t)((it + 3) % ring) * a_el, K, W, K, C + (size_t)((it + 3) % ring) * c_el, N, M, N, K, e, 0);
     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_p, e0, e1);
-    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k_probe2<0>, dim3(tiles), dim3(256), NS * 16384, 0, A + (size_t)(it % ring) * a_el, (long)K, Bp, C2 + (size_t)(it % ring) * c_el, (long)N, M, N, K, tiles_n);
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k_probe2<3>, dim3(tiles), dim3(256), NS * 16384, 0, A + (size_t)(it % ring) * a_el, (long)K, Bp, C2 + (size_t)(it % ring) * c_el, (long)N, M, N, K, tiles_n);
     hipEventRecord(e0);
     for (int it = 0; it < reps; ++it)
-      hipLaunchKernelGGL(k_probe2<0>, dim3(tiles), dim3(256), NS * 16384, 0, A + (size_t)((it + 3) % ring) * a_el, (long)K, Bp, C2 + (size_t)((it + 3) % ring) * c_el, (long)N, M, N, K, tiles_n);
+      hipLaunchKernelGGL(k_probe2<3>, dim3(tiles), dim3(256), NS * 16384, 0, A + (size_t)((it + 3) % ring) * a_el, (long)K, Bp, C2 + (size_t)((it + 3) % ring) * c_el, (long)N, M, N, K, tiles_n);
     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_q, e0, e1);
+  }
+  float ms_r = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k_probe2<1>, dim3(tiles), dim3(256), 2 * 16384, 0, A + (size_t)(it % ring) * a_el, (long)K, Bp, C2 + (size_t)(it % ring) * c_el, (long)N, M, N, K, tiles_n);
+    hipEventRecord(e0);
+    for (int it = 0; it < reps; ++it)
+      hipLaunchKernelGGL(k_probe2<1>, dim3(tiles), dim3(256), 2 * 16384, 0, A + (size_t)((it + 3) % ring) * a_el, (long)K, Bp, C2 + (size_t)((it + 3) % ring) * c_el, (long)N, M, N, K, tiles_n);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_r, e0, e1);
   }
   // same numbers?
   std::vector<bf16_t> c1((size_t)M * N), c2((size_t)M * N);
@@ -129,7 +147,7 @@ int main(int argc, char** argv) {
   size_t bad = 0;
   for (size_t i = 0; i < c1.size(); ++i) bad += c1[i] != c2[i];
   const double fl = 2.0 * M * N * K;
-  printf("M %6d N %5d K %5d (%4d tiles): product kernel %7.1f us (%6.1f TFLOP/s)   ring + packed-B probe %7.1f us (%6.1f TFLOP/s)   ratio %.2f   differing outputs %zu\n", M, N, K, tiles,
-         ms_p / reps * 1e3, fl / (ms_p / reps) / 1e9, ms_q / reps * 1e3, fl / (ms_q / reps) / 1e9, ms_p / ms_q, bad);
+  printf("M %6d N %5d K %5d (%4d tiles): product %7.1f us (%6.1f TFLOP/s)   A ring of 4 + packed B %7.1f us (x %.2f)   A ring of 2 (32 KB LDS) + packed B %7.1f us (x %.2f)   differing outputs %zu\n", M, N, K,
+         tiles, ms_p / reps * 1e3, fl / (ms_p / reps) / 1e9, ms_q / reps * 1e3, ms_p / ms_q, ms_r / reps * 1e3, ms_p / ms_r, bad);
   return 0;
 }
