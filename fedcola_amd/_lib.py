@@ -100,6 +100,8 @@ SIGNATURES = {
     "fc_k_attention_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fc_k_attention_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fc_k_dw": (C.c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fc_k_mlp_pack": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
+    "fc_k_mlp_fused": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "fc_k_adamw": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "fc_k_cast": (C.c_int, [_I, _P, _P, _L, _P]),
     "fc_image_u8_to_f32": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),

@@ -115,7 +115,7 @@ __device__ inline float gelu_erf_grad(float x) {
 // parity path keeps erff.
 __device__ inline void gelu_fast_parts(float x, float& cdf, float& pdf) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to the 10-instruction IEEE division sequence
   const float ex = __expf(-z * z);                          // = exp(-x^2/2)
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erfz = 1.0f - poly * ex;                     // erf(|x|/sqrt 2)

@@ -159,6 +159,15 @@ struct GemmProb { const bf16_t* A; const bf16_t* B; void* C; long lda, ldb, ldc;
 struct GemmGroup { GemmProb p[2]; int N, K, tiles_n, tiles0, ntiles; };
 int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t s);
 
+// ---- fused MLP (fc_mlp.hip): fc1 -> GELU -> fc2 per 64-row panel, or its backward mirror; D = 384 only.  The weights come from streams packed
+// in MFMA-fragment order (fc_mlp_pack: one launch for a table of {W1, W2, forward stream, backward stream} jobs, fc_mlp_pack_elems bf16 each).
+size_t fc_mlp_pack_elems(int D, int Hd);
+int fc_mlp_fused_ok(int D, int Hd);
+int fc_mlp_pack(const void* jobs_dev, int njobs, int D, int Hd, hipStream_t s);
+struct FcMlpPackJob { const bf16_t* W1; const bf16_t* W2; bf16_t* fwd; bf16_t* bwd; };
+int fc_mlp_fused(int bwd, const void* X, const void* Wp, const float* b1, const float* b2, void* act, void* gsave, const void* res, const float* rowscale,
+                 int rps, void* out, int M, int D, int Hd, hipStream_t s);          // 1 = shape not covered
+
 // grouped weight-gradient GEMM: C[M,N] (fp32) = A[K,M]^T . B[K,N], bias_grad[M] = column sums of A (may be null)
 struct FcTnProblem {
   const bf16_t* A;

@@ -109,6 +109,15 @@ struct fc_model {
   mutable void* reparam_dev = nullptr;
   int dt;  // FC_F32 / FC_BF16 activation + compute-weight type
   bool need_wc;
+  // fused MLP (fc_mlp.hip): the bf16 mode of a 384-wide model reads fc1 / fc2 from streams packed in MFMA-fragment order, kept behind the
+  // compute weights in the same buffer: per tower and layer a forward and a backward stream of 2 * D * Hd bf16 each
+  bool mlp_fused = false;
+  size_t mlp_stream_elems() const { return fc_mlp_pack_elems(cfg.dim, cfg.mlp_hidden); }
+  size_t mlp_pack_base() const { return ((size_t)total * fc_esize(dt) + 255) / 256 * 256; }      // byte offset of the first stream inside wc
+  size_t mlp_pack_bytes() const { return mlp_fused ? (size_t)2 * cfg.depth * 2 * mlp_stream_elems() * sizeof(bf16_t) : 0; }
+  const bf16_t* mlp_stream(const void* wc, int tower, int layer, int bwd) const {
+    return (const bf16_t*)((const char*)wc + mlp_pack_base()) + ((size_t)(tower * cfg.depth + layer) * 2 + bwd) * mlp_stream_elems();
+  }
   int64_t add(const std::string& name, std::vector<int64_t> shape, int trainable = 1) {
     fc_segment s;
     memset(&s, 0, sizeof(s));
@@ -151,6 +160,10 @@ extern "C" int fc_model_create(const fc_model_cfg* c, fc_model_t** out) {
   bool aux = c->with_aux && uni;                       // mome.py:768
   bool aux_attn = aux && !c->aux_mlp_only, aux_mlp = aux && !c->aux_attn_only;
   m->need_wc = (m->dt == FC_BF16) || aux;
+  {
+    static const int on = fc_knob("FC_MLP_FUSED", 1);
+    m->mlp_fused = on && m->dt == FC_BF16 && fc_mlp_fused_ok(c->dim, c->mlp_hidden);
+  }
   int present[2] = {c->has_img, c->has_txt};
   // embeddings first (mome.py:709-723)
   for (int i = 0; i < 2; ++i) {
@@ -234,7 +247,10 @@ extern "C" int fc_model_set_trainable(fc_model_t* m, int32_t seg, int32_t traina
   m->segs[seg].trainable = trainable;
   return 0;
 }
-extern "C" size_t fc_compute_weights_bytes(const fc_model_t* m) { return m->need_wc ? (size_t)m->total * fc_esize(m->dt) : 0; }
+extern "C" size_t fc_compute_weights_bytes(const fc_model_t* m) {
+  if (!m->need_wc) return 0;
+  return m->mlp_fused ? m->mlp_pack_base() + m->mlp_pack_bytes() : (size_t)m->total * fc_esize(m->dt);
+}
 
 // ---------------------------------------------------------------- workspace
 struct LayerWs {
@@ -457,6 +473,23 @@ static int reparam_table(const fc_model* m, const FcReparam** tab, int* n) {
   *tab = (const FcReparam*)m->reparam_dev;
   return 0;
 }
+static int cached_table(const void* host, size_t bytes, const void** out);
+// the fused MLP's weight streams of every layer of both towers, from the bf16 compute weights in `wc` (one launch)
+static int mlp_pack_all(const fc_model* m, void* wc, hipStream_t s) {
+  if (!m->mlp_fused) return 0;
+  std::vector<FcMlpPackJob> jobs;
+  const bf16_t* W = (const bf16_t*)wc;
+  for (int i = 0; i < 2; ++i) {
+    if (!m->tw[i].present) continue;
+    for (int l = 0; l < m->cfg.depth; ++l) {
+      const BlockP& b = m->tw[i].blocks[l];
+      jobs.push_back(FcMlpPackJob{W + b.fc1.w, W + b.fc2.w, (bf16_t*)m->mlp_stream(wc, i, l, 0), (bf16_t*)m->mlp_stream(wc, i, l, 1)});
+    }
+  }
+  const void* tab = nullptr;
+  FC_TRY(cached_table(jobs.data(), jobs.size() * sizeof(FcMlpPackJob), &tab));
+  return fc_mlp_pack(tab, (int)jobs.size(), m->cfg.dim, m->cfg.mlp_hidden, s);
+}
 extern "C" int fc_prepare_weights(const fc_model_t* m, const float* params, void* wc, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!m->need_wc) return 0;
@@ -464,7 +497,8 @@ extern "C" int fc_prepare_weights(const fc_model_t* m, const float* params, void
   FC_TRY(fc_cast(m->dt, params, wc, (size_t)m->total, s));
   const FcReparam* tab; int n;
   FC_TRY(reparam_table(m, &tab, &n));
-  return fc_reparam_fold_grouped(m->dt, tab, n, params, wc, s);      // W + s*A of every re-param linear in one launch
+  FC_TRY(fc_reparam_fold_grouped(m->dt, tab, n, params, wc, s));      // W + s*A of every re-param linear in one launch
+  return mlp_pack_all(m, wc, s);
 }
 
 extern "C" int fc_upload_fold(const fc_model_t* m, const float* params, float* dst, void* stream) {
@@ -725,6 +759,18 @@ static int chain_layer_forward(const Ctx& c, Ws& w, const TowerList& T, int l) {
     ln[q] = LnFwdD{L.xmid, P + b.n2w, P + b.n2b, L.h2, L.mean2, L.rstd2, t.M};
   }
   FC_TRY(ln_fwd_multi(c, ln, nt, D, 1e-5f));
+  if (m->mlp_fused) {      // fc1 -> GELU -> fc2 + residual in one launch per tower (fc_mlp.hip)
+    bool all = true;
+    for (int q = 0; q < nt && all; ++q) {
+      const BlockP& b = m->tw[tw[q]].blocks[l]; TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
+      const int r = fc_mlp_fused(0, L.h2, m->mlp_stream(c.wc, tw[q], l, 0), P + b.fc1.b, P + b.fc2.b, L.gact, L.u, L.xmid, dp_ptr(m, w, tw[q], l, 1), t.N,
+                                 t.x[l + 1], t.M, D, Hd, c.s);
+      if (r < 0) return r;
+      FC_REQUIRE(r == 0 || q == 0, "internal: the fused MLP covered one tower of a layer and declined the other");
+      all = r == 0;
+    }
+    if (all) return 0;
+  }
   for (int q = 0; q < nt; ++q) {
     const BlockP& b = m->tw[tw[q]].blocks[l]; TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
     gd[q] = GemmD{L.h2, c.W(b.fc1.w), L.gact, t.M, GemmEpi()};
@@ -1412,14 +1458,26 @@ static int chain_layer_backward(const Ctx& c, Ws& w, const TowerList& T, int l, 
     gd[q] = GemmD{dm[q], c.W(b.fc2.w), L.gdu, t.M, GemmEpi()};
     gd[q].e.gelu_in = L.u; gd[q].e.gelu_saved_grad = (c.dt == FC_BF16);                 // du = (dm.W2) * gelu'(u)
   }
-  FC_TRY(gemm_multi(c, FC_GEMM_NN, gd, nt, Hd, D));
+  bool mlp_done = false;
+  if (m->mlp_fused) {      // du = (dm . W2) * gelu'(u) (stored: fc1's weight gradient reads it) and dh2 = du . W1 in one launch per tower
+    mlp_done = true;
+    for (int q = 0; q < nt && mlp_done; ++q) {
+      const int i = tw[q];
+      TowerWs& t = w.t[i]; LayerWs& L = t.L[l];
+      const int r = fc_mlp_fused(1, dm[q], m->mlp_stream(c.wc, i, l, 1), nullptr, nullptr, L.gdu, L.u, nullptr, nullptr, 1, t.dh, t.M, D, Hd, c.s);
+      if (r < 0) return r;
+      FC_REQUIRE(r == 0 || q == 0, "internal: the fused MLP covered one tower of a layer and declined the other");
+      mlp_done = r == 0;
+    }
+  }
+  if (!mlp_done) FC_TRY(gemm_multi(c, FC_GEMM_NN, gd, nt, Hd, D));
   for (int q = 0; q < nt; ++q) {
     const int i = tw[q];
     const BlockP& b = m->tw[i].blocks[l]; TowerWs& t = w.t[i]; LayerWs& L = t.L[l];
     FC_TRY(linear_bwd_params(c, b.fc1, L.gdu, L.h2, t.M, grads));
     gd[q] = GemmD{L.gdu, c.W(b.fc1.w), t.dh, t.M, GemmEpi()};                            // dh2
   }
-  FC_TRY(gemm_multi(c, FC_GEMM_NN, gd, nt, D, Hd));
+  if (!mlp_done) FC_TRY(gemm_multi(c, FC_GEMM_NN, gd, nt, D, Hd));
   // ---- attention branch: xmid = x_l + s1 * (o.Wp^T + bp); da = gxmid * s1 comes out of the same LayerNorm-backward pass
   for (int q = 0; q < nt; ++q) {
     const int i = tw[q];
@@ -1921,6 +1979,7 @@ extern "C" int fc_adamw_step_segs(const fc_model_t* m, float* params, float* gra
     i = j + 1;
   }
   if (wc && m->need_wc && !shadow) FC_TRY(fc_prepare_weights(m, params, wc, stream));
+  else if (shadow) FC_TRY(mlp_pack_all(m, wc, (hipStream_t)stream));
   return 0;
 }
 
@@ -2048,6 +2107,7 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
     FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s, fuse_shadow ? (bf16_t*)wc : nullptr));
   }
   if (m->need_wc && !fuse_shadow) FC_TRY(fc_prepare_weights(m, params, wc, stream));
+  else if (fuse_shadow) FC_TRY(mlp_pack_all(m, wc, s));      // the optimizer wrote the bf16 shadow: refresh the fused MLP's streams from it
   FC_PHASE(4);
   return 0;
 }
@@ -2246,6 +2306,20 @@ extern "C" int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, f
   FC_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
   FC_CHECK_HIP(hipFree(dev));
   return r;
+}
+extern "C" int fc_k_mlp_pack(const void* W1, const void* W2, void* stream_fwd, void* stream_bwd, int32_t D, int32_t Hd, void* stream) {
+  FcMlpPackJob job{(const bf16_t*)W1, (const bf16_t*)W2, (bf16_t*)stream_fwd, (bf16_t*)stream_bwd};
+  FcMlpPackJob* dev = nullptr;
+  FC_CHECK_HIP(hipMalloc(&dev, sizeof(job)));
+  FC_CHECK_HIP(hipMemcpy(dev, &job, sizeof(job), hipMemcpyHostToDevice));
+  const int r = fc_mlp_pack(dev, 1, D, Hd, (hipStream_t)stream);
+  FC_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  FC_CHECK_HIP(hipFree(dev));
+  return r;
+}
+extern "C" int fc_k_mlp_fused(int32_t bwd, const void* X, const void* Wp, const float* b1, const float* b2, void* act, void* gsave, const void* res,
+                              const float* rowscale, int32_t rows_per_sample, void* out, int32_t M, int32_t D, int32_t Hd, void* stream) {
+  return fc_mlp_fused(bwd, X, Wp, b1, b2, act, gsave, res, rowscale, rows_per_sample, out, M, D, Hd, (hipStream_t)stream);
 }
 extern "C" int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd, int32_t step,
                           void* stream) {

@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 4   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw;
-                              4: fc_image_u8_to_f32, fc_k_gemm_epi; fc_k_layernorm_partial_floats counts fp64 rows */
+#define FC_ABI_VERSION 5   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw;
+                              4: fc_image_u8_to_f32, fc_k_gemm_epi; fc_k_layernorm_partial_floats counts fp64 rows;
+                              5: fc_k_mlp_pack, fc_k_mlp_fused */
 
 enum { FC_PREC_FP32 = 0, FC_PREC_BF16 = 1 };
 enum { FC_TASK_NONE = 0, FC_TASK_CLS = 1, FC_TASK_RTV = 2 };
@@ -274,6 +275,16 @@ int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, const void* o,
  * 3 = the fp32 mode's form: dY, X are FP32, products by split-operand MFMAs, the row reduction cut into slices added in fp64, and db is ADDED TO.
  * Test entry point: allocates its one-entry problem table and synchronises the stream. */
 int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, float* db, int32_t rows, int32_t out, int32_t in, void* stream);
+/* the fused MLP of a Block (mome.py:117-123), bf16, D = 384, Hd % 128 == 0, one launch per call; returns 1 when the shape is not covered.
+ * The weights are read from a copy packed in MFMA-fragment order: fc_k_mlp_pack writes both directions' streams (2 * D * Hd bf16 each) from
+ * the row-major W1 [Hd,D] and W2 [D,Hd] (test entry point: allocates its one-entry job table and synchronises the stream).
+ * bwd = 0: out[M,D] = res + rowscale[m / rows_per_sample] * (gelu(X.W1^T + b1).W2^T + b2)   (X: the LayerNorm-2 output; Wp: the forward stream);
+ *          act <- gelu(u), gsave <- gelu'(u) (both [M,Hd], kept for the backward); rowscale may be NULL.
+ * bwd = 1: out[M,D] = ((X.W2) * gsave).W1   (X: dY of the block's MLP branch [M,D]; Wp: the backward stream); gsave is READ,
+ *          act <- (X.W2) * gsave (= du, the operand of fc1's weight gradient); b1, b2, res, rowscale unused (NULL). */
+int fc_k_mlp_pack(const void* W1, const void* W2, void* stream_fwd, void* stream_bwd, int32_t D, int32_t Hd, void* stream);
+int fc_k_mlp_fused(int32_t bwd, const void* X, const void* Wp, const float* b1, const float* b2, void* act, void* gsave, const void* res,
+                   const float* rowscale, int32_t rows_per_sample, void* out, int32_t M, int32_t D, int32_t Hd, void* stream);
 int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
                int32_t step, void* stream);
 int fc_k_cast(int32_t dt_out, const float* src, void* dst, int64_t n, void* stream);

@@ -227,3 +227,74 @@ def test_cast_bf16_rne():
     L().check(L().lib().fc_k_cast(1, P(dev(x)), P(y), 1000, S()))
     torch.cuda.synchronize()
     assert torch.equal(y.cpu(), x.to(torch.bfloat16))
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("M", [64, 197, 333, 197 * 22, 2048])      # ragged last panel, one full-size chain, the text tower
+@pytest.mark.parametrize("Hd", [1536, 256])
+@pytest.mark.parametrize("rowscale", [False, True])
+def test_mlp_fused(M, Hd, rowscale):
+    """Fused MLP (fc_mlp.hip): Mlp.forward mome.py:117-123 + the residual of Block.forward mome.py:228, and its backward mirror, against
+    (a) the exact formulas in fp64 with bf16 rounding at the kernel's store points and (b) the separate GEMM kernels it replaces."""
+    if rowscale and Hd == 256:
+        pytest.skip("one drop-path case is enough")
+    D, N_tok = 384, 197 if M % 197 == 0 else 32
+    g = torch.Generator().manual_seed(M + Hd)
+    X = (torch.randn(M, D, generator=g)).to(torch.bfloat16)
+    W1 = (torch.randn(Hd, D, generator=g) * D ** -0.5).to(torch.bfloat16)
+    W2 = (torch.randn(D, Hd, generator=g) * Hd ** -0.5).to(torch.bfloat16)
+    b1 = torch.randn(Hd, generator=g) * 0.2
+    b2 = torch.randn(D, generator=g) * 0.2
+    res = torch.randn(M, D, generator=g).to(torch.bfloat16)
+    dm = torch.randn(M, D, generator=g).to(torch.bfloat16)
+    nsamp = (M + N_tok - 1) // N_tok
+    rs = (torch.rand(nsamp, generator=g) > 0.3).float() / 0.7 if rowscale else None
+    lib = L().lib()
+    Xd, W1d, W2d, b1d, b2d, resd, dmd = dev(X), dev(W1), dev(W2), dev(b1), dev(b2), dev(res), dev(dm)
+    rsd = dev(rs) if rowscale else None
+    act = torch.full((M, Hd), 7.0, device="cuda", dtype=torch.bfloat16); gs = torch.full_like(act, 7.0)
+    out = torch.full((M, D), 7.0, device="cuda", dtype=torch.bfloat16)
+    pf = torch.empty(2 * D * Hd, device="cuda", dtype=torch.bfloat16); pb = torch.empty_like(pf)
+    L().check(lib.fc_k_mlp_pack(P(W1d), P(W2d), P(pf), P(pb), D, Hd, S()))
+    rc = lib.fc_k_mlp_fused(0, P(Xd), P(pf), P(b1d), P(b2d), P(act), P(gs), P(resd), P(rsd), N_tok, P(out), M, D, Hd, S())
+    L().check(rc)
+    torch.cuda.synchronize()
+    # (a) exact formulas
+    u = X.double() @ W1.double().t() + b1.double()
+    cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2))); pdf = torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+    h_ref, gp_ref = u * cdf, cdf + u * pdf
+    y = _bf(h_ref) @ W2.double().t() + b2.double()
+    if rowscale:
+        y = y * rs.double().repeat_interleave(N_tok)[:M, None]
+    o_ref = y + res.double()
+    e = maxerr(act, h_ref); assert e <= 1e-2 * amax(h_ref), f"gelu(u) err {e}"
+    e = maxerr(gs, gp_ref); assert e <= 1e-2 * amax(gp_ref), f"gelu'(u) err {e}"
+    e = maxerr(out, o_ref); assert e <= 1.2e-2 * amax(o_ref), f"out err {e}"
+    # (b) the separate kernels: fc1 with the GELU epilogue, fc2 with bias + residual (no drop-path form in that entry point)
+    act2 = torch.empty_like(act); gs2 = torch.empty_like(gs); out2 = torch.empty_like(out)
+    L().check(lib.fc_k_gemm_epi(0, P(Xd), P(W1d), P(act2), M, Hd, D, P(b1d), None, P(gs2), None, S()))
+    torch.cuda.synchronize()
+    assert torch.equal(act, act2), f"gelu(u): {int((act != act2).sum())} elements differ from the separate kernel"
+    assert torch.equal(gs, gs2), f"gelu'(u): {int((gs != gs2).sum())} elements differ from the separate kernel"
+    if not rowscale:
+        L().check(lib.fc_k_gemm_epi(0, P(act2), P(W2d), P(out2), M, D, Hd, P(b2d), P(resd), None, None, S()))
+        torch.cuda.synchronize()
+        nd = int((out != out2).sum())      # (the residual add may contract differently: a rare one-ulp flip is allowed, nothing more)
+        assert nd <= 1e-3 * out.numel() and maxerr(out, out2.double().cpu()) <= 2e-2 * amax(o_ref), f"out: {nd} elements differ from the separate kernels"
+    # ---- backward: du = (dm . W2) * gelu'(u), dx = du . W1
+    du = torch.full((M, Hd), 7.0, device="cuda", dtype=torch.bfloat16); dx = torch.full((M, D), 7.0, device="cuda", dtype=torch.bfloat16)
+    L().check(lib.fc_k_mlp_fused(1, P(dmd), P(pb), None, None, P(du), P(gs), None, None, 1, P(dx), M, D, Hd, S()))
+    torch.cuda.synchronize()
+    du_ref = (dm.double() @ W2.double()) * gs.double().cpu()
+    dx_ref = _bf(du_ref) @ W1.double()
+    e = maxerr(du, du_ref); assert e <= 1e-2 * amax(du_ref), f"du err {e}"
+    e = maxerr(dx, dx_ref); assert e <= 1.2e-2 * amax(dx_ref), f"dx err {e}"
+    du2 = torch.empty_like(du); dx2 = torch.empty_like(dx)
+    L().check(lib.fc_k_gemm_epi(1, P(dmd), P(W2d), P(du2), M, Hd, D, None, None, None, P(gs), S()))
+    L().check(lib.fc_k_gemm_epi(1, P(du2), P(W1d), P(dx2), M, D, Hd, None, None, None, None, S()))
+    torch.cuda.synchronize()
+    assert torch.equal(du, du2), f"du: {int((du != du2).sum())} elements differ from the separate kernel"
+    assert torch.equal(dx, dx2), f"dx: {int((dx != dx2).sum())} elements differ from the separate kernels"

@@ -182,7 +182,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fedcola_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.fc_abi_version() == 4
+    assert lib.fc_abi_version() == 5
 
 
 def test_model_layout_and_errors_without_gpu():

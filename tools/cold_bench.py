@@ -53,10 +53,16 @@ K["ln_bwd"] = lambda i: ck(L.fc_k_layernorm_bwd_partial(1, R(Y, i), R(X, i), P(m
 K["proj dX (plain)"] = lambda i: ck(L.fc_k_gemm_epi(1, R(X, i), R(Wp, i), R(Y, i), M, D, D, None, None, None, None, sp))
 K["attn bwd"] = lambda i: ck(L.fc_k_attention_bwd(1, 1, R(QKV, i), R(X, i), R(Y, i), P(lse), P(delta), R(DQKV, i), B, N_tok, H, 64, 0.125, sp))
 K["qkv dX (plain)"] = lambda i: ck(L.fc_k_gemm_epi(1, R(QKV, i), R(Wqkv, i), R(Y, i), M, D, 3 * D, None, None, None, None, sp))
+DU = ring((M, Hd))
+PF = [torch.empty(2 * D * Hd, device=dev, dtype=bf) for _ in W1]; PB = [torch.empty(2 * D * Hd, device=dev, dtype=bf) for _ in W1]
+for a_, b_, c_, d_ in zip(W1, W2, PF, PB): ck(L.fc_k_mlp_pack(P(a_), P(b_), P(c_), P(d_), D, Hd, sp))
+K["mlp fused fwd (fc1+gelu+fc2+res)"] = lambda i: ck(L.fc_k_mlp_fused(0, R(X, i), R(PF, i), P(b1536), P(b384), R(U, i), R(U2, i), R(X2, i), None, N_tok, R(Y, i), M, D, Hd, sp))
+K["mlp fused bwd (fc2dX*g'+fc1dX)"] = lambda i: ck(L.fc_k_mlp_fused(1, R(X, i), R(PB, i), None, None, R(DU, i), R(U2, i), None, None, 1, R(Y, i), M, D, Hd, sp))
 only = os.environ.get("COLD_ONLY")
 flops = {"qkv fwd (bias)": 2 * M * 3 * D * D, "proj fwd (bias+res)": 2 * M * D * D, "fc1 fwd (gelu, 2 stores)": 2 * M * Hd * D,
          "fc2 fwd (bias+res)": 2 * M * Hd * D, "fc2 dX (x gelu')": 2 * M * Hd * D, "fc1 dX (plain)": 2 * M * Hd * D,
          "proj dX (plain)": 2 * M * D * D, "qkv dX (plain)": 2 * M * 3 * D * D,
+         "mlp fused fwd (fc1+gelu+fc2+res)": 4 * M * Hd * D, "mlp fused bwd (fc2dX*g'+fc1dX)": 4 * M * Hd * D,
          "attn fwd": 4 * B * H * N_tok * N_tok * 64, "attn bwd": 10 * B * H * N_tok * N_tok * 64}
 print(f"# rows {M} ({B} x {N_tok}), {reps} launches per kernel, each on another buffer set (ring footprint ~{GB} GB per tensor group of 8); HIP-event time per launch")
 for name, fn in K.items():
