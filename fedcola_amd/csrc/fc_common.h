@@ -113,13 +113,18 @@ __device__ inline float gelu_erf_grad(float x) {
 // erf-GELU with the Abramowitz-Stegun 7.1.26 rational form of erf (|error| <= 1.5e-7, far below bf16 resolution): one
 // v_exp + one v_rcp + a few FMAs instead of libm's erff (~40 VALU ops).  Used by the bf16 MFMA epilogues only; the fp32
 // parity path keeps erff.
+// (round 5: exp(-x^2/2) as v_exp_f32 of -(k x)^2 with k = sqrt(log2(e) / 2) -- one multiply instead of three -- and the argument of the
+// reciprocal as one fma of |x|: nine VALU + two transcendental instructions per element instead of thirteen + two, and v_rcp_f32 instead
+// of __frcp_rn, which expands to the ten-instruction IEEE division.  fc_mlp.hip's ml_gelu runs the same sequence stage by stage.)
+#define FC_GELU_K 0.84932180028801904272f      /* sqrt(log2(e) / 2) */
+#define FC_GELU_P 0.23164189045929018f         /* 0.3275911 / sqrt(2) */
 __device__ inline void gelu_fast_parts(float x, float& cdf, float& pdf) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to the 10-instruction IEEE division sequence
-  const float ex = __expf(-z * z);                          // = exp(-x^2/2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), FC_GELU_P, 1.0f));
+  const float w = x * FC_GELU_K;
+  const float ex = __builtin_amdgcn_exp2f(-w * w);         // = exp(-x^2/2)
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erfz = 1.0f - poly * ex;                     // erf(|x|/sqrt 2)
-  cdf = 0.5f * (1.0f + copysignf(erfz, x));
+  cdf = 0.5f + copysignf(0.5f * erfz, x);
   pdf = ex * 0.39894228040143267794f;
 }
 __device__ inline float gelu_fast(float x) { float c, p; gelu_fast_parts(x, c, p); return x * c; }

@@ -32,8 +32,8 @@
 
 #define ML_ROWS 64
 #define ML_HC 128
-#define ML_NB 3            // weight pieces in flight per wave of the second role (register ring); divides the 2 ND pieces a role has per chunk
-#define ML_NBA 3           // ... of the first role, which also issues the activation stores: its loads queue behind them in vmcnt order
+#define ML_NB 6            // weight pieces in flight per wave of the second role (register ring); divides the 2 ND pieces a role has per chunk
+#define ML_NBA 6           // ... of the first role, which also issues the activation stores: its loads queue behind them in vmcnt order
 #define ML_PIECE 16384     // packed bytes per piece: 4 waves x (2 k-steps x 2 column blocks) x 1 KB
 #define ML_TILE 8192       // one [64 rows][64 k] KC image
 
@@ -86,20 +86,64 @@ __device__ __forceinline__ unsigned ml_lane_off(int lane, int ks) {   // kc_off(
   const int r = lane & 15, g = lane >> 4;
   return (unsigned)(r * 128 + ((((ks << 2) | g) ^ (r >> 1)) << 4));
 }
-struct MlA { bf16x8 f[2][4]; };      // the LDS operand's fragments of one piece: [k-step][16-row block]
+struct MlA { bf16x8 f[4]; };         // the LDS operand's fragments of ONE 32-k step of a piece: [16-row block]
 struct MlB { bf16x8 f[2][2]; };      // the weight fragments of one piece: [k-step][16-column block]
-__device__ __forceinline__ void ml_read_a(MlA& A, const char* t0, const char* t1) {   // t0 / t1: image base + lane offset of k-step 0 / 1
+__device__ __forceinline__ void ml_read_a(MlA& A, const char* t) {   // t: image base + this lane's offset for the k-step
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { A.f[0][i] = *(const bf16x8*)(t0 + i * 2048); A.f[1][i] = *(const bf16x8*)(t1 + i * 2048); }
+  for (int i = 0; i < 4; ++i) A.f[i] = *(const bf16x8*)(t + i * 2048);
 }
-// acc[i][j][x] = C[16 i + (lane & 15)][16 j + 4 (lane >> 4) + x] of the wave's 64 x 32 block (swapped operands, as in fc_mfma.hip)
-__device__ __forceinline__ void ml_mfma(const MlA& A, const MlB& Bf, f32x4 (&acc)[4][2]) {
+// acc[i][j][x] = C[16 i + (lane & 15)][16 j + 4 (lane >> 4) + x] of the wave's 64 x 32 block (swapped operands, as in fc_mfma.hip).
+// A fragment register is re-read for the NEXT piece (`next`: that piece's image + this lane's offset for the k-step; null: no re-read) as
+// soon as its two MFMAs have issued, so every LDS read has 14 MFMAs (224 cycles) to land: with whole k-step sets re-read behind their eight
+// MFMAs a wave alone on the matrix pipe took 520 cycles per 16-MFMA piece (profiles/r05/mlp_fused_v4d_stamps.txt).
+template <int KS, bool REREAD>
+__device__ __forceinline__ void ml_mfma(MlA& A, const MlB& Bf, f32x4 (&acc)[4][2], const char* next) {
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf.f[KS][j], A.f[i], acc[i][j], 0, 0, 0);
+    if (REREAD) A.f[i] = *(const bf16x8*)(next + i * 2048);
+  }
+}
+
+// gelu(v) and gelu'(v) of N elements, stage by stage over all of them (the same arithmetic as gelu_fast_parts, element by element: the
+// Horner chain of one element is nine dependent instructions; written per element hipcc scheduled the chains one after the other with an
+// s_nop between the packed operations, 137 cycles per element -- profiles/r05/mlp_fused_v4c_stamps.txt)
+template <int N>
+__device__ __forceinline__ void ml_gelu(const float (&v)[N], float (&h)[N], float (&gp)[N]) {
+  float t[N], ex[N], poly[N];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf.f[ks][j], A.f[ks][i], acc[i][j], 0, 0, 0);
+  for (int k = 0; k < N; ++k) t[k] = __builtin_amdgcn_rcpf(fmaf(fabsf(v[k]), FC_GELU_P, 1.0f));
+#pragma unroll
+  for (int k = 0; k < N; ++k) { const float w = v[k] * FC_GELU_K; ex[k] = __builtin_amdgcn_exp2f(-w * w); }
+#pragma unroll
+  for (int k = 0; k < N; ++k) poly[k] = -1.453152027f + t[k] * 1.061405429f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) poly[k] = 1.421413741f + t[k] * poly[k];
+#pragma unroll
+  for (int k = 0; k < N; ++k) poly[k] = -0.284496736f + t[k] * poly[k];
+#pragma unroll
+  for (int k = 0; k < N; ++k) poly[k] = 0.254829592f + t[k] * poly[k];
+#pragma unroll
+  for (int k = 0; k < N; ++k) poly[k] = t[k] * poly[k];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float erfz = 1.0f - poly[k] * ex[k];
+    const float cdf = 0.5f + copysignf(0.5f * erfz, v[k]);
+    const float pdf = ex[k] * 0.39894228040143267794f;
+    gp[k] = cdf + v[k] * pdf;
+    h[k] = v[k] * cdf;
+  }
+}
+
+#ifndef ML_PHASES
+#define ML_PHASES 1
+#endif
+__device__ __forceinline__ void ml_barrier_x() {      // phase boundary: no LDS hand-off rides on it
+#if ML_PHASES
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#endif
 }
 
 struct MlpArgs {
@@ -113,7 +157,7 @@ struct MlpArgs {
   const float* rowscale;    // forward: drop-path scale per sample (may be null)
   bf16_t* out;              // [M, D]
   int M, Hd, rps;
-  int dbg;                  // tools build only (FC_MLP_DBG): 1 no activation arithmetic, 2 no MFMA, 4 no weight loads, 8 no LDS fragment reads
+  int dbg;                  // tools build only (FC_MLP_DBG): 1 no activation arithmetic, 4 no weight loads
   long long* stamps;        // tools build only
 };
 #ifdef FC_PROBES
@@ -164,28 +208,23 @@ __global__ void __launch_bounds__(512) k_mlp_fused(const MlpArgs a) {
         dst.f[ks][j] = *(bf16x8*)&v;
       }
   };
-  if (role == 0) {
-#pragma unroll
-    for (int k = 0; k < ML_NBA; ++k) load_b(Bq[k], k);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * ML_NBA) : "memory");        // the X panel has landed (the weight loads are younger)
-  } else {
-#pragma unroll
-    for (int k = 0; k < ML_NB; ++k) load_b(Bq[k], NT1 + k);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * ML_NB) : "memory");
-  }
-  ML_STAMP(0);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  ML_STAMP(1);
+  // (one if / else over the role from here to the output phase: with the ring filled in a separate if the allocator kept both roles' registers
+  // alive in both branches and spilled 114 of them)
   const char* xa0 = smem + ml_lane_off(lane, 0);
   const char* xa1 = smem + ml_lane_off(lane, 1);
   typedef __attribute__((vector_size(8))) unsigned int v2u;
-  f32x4 yacc[ND][4][2];
-  MlA A0, A1;
+  MlA A0, A1;      // the fragments of k-step 0 / k-step 1 of the current piece: each is re-read for the next piece as soon as its MFMAs have issued
   // a role's piece P (0 .. NT1-1 inside its half of the chunk): ring slot P % ML_NB, refilled with the role's piece P + ML_NB
 #define ML_REFILL(P, NBX, ROLE) load_b(Bq[(P) % (NBX)], ((P) + (NBX) < NT1 ? c * PPC : (c + 1) * PPC - NT1) + (ROLE) * NT1 + (P) + (NBX))
   if (role == 0) {
     // ================================================== first product + activation
+#pragma unroll
+    for (int k = 0; k < ML_NBA; ++k) load_b(Bq[k], k);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * ML_NBA) : "memory");        // the X panel has landed (the weight loads are younger)
+    ML_STAMP(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ML_STAMP(1);
     f32x4 uacc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -201,30 +240,12 @@ __global__ void __launch_bounds__(512) k_mlp_fused(const MlpArgs a) {
     unsigned hoff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) hoff[j] = (unsigned)(XB + (w >> 1) * ML_TILE + r * 128 + (((4 * (w & 1) + 2 * j + (g >> 1)) ^ (r >> 1)) << 4) + (g & 1) * 8);
-    // The activation leaves for global memory one chunk later, row-wise out of the LDS images: 16 lanes store one 256-byte row segment with
-    // 16-byte accesses.  (Stored straight from the accumulator layout -- 8 bytes per lane, 32-byte runs -- the sixteen dwordx2 stores per
-    // wave and chunk took 1.6 us per chunk at issue, 19 us of a 51-us launch: profiles/r05/mlp_fused_v4a_ablate.txt.)
-    auto store_images = [&](int cc) {
-      const int hs = (cc & 1) * 2 * ML_TILE;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int item = it * 256 + tid, c8 = item & 7, t = (item >> 3) & 1, rho = item >> 4;
-        const int lo = hs + t * ML_TILE + rho * 128 + ((c8 ^ ((rho >> 1) & 7)) << 4);
-        const unsigned go = (m0 + rho < M) ? (unsigned)(((m0 + rho) * Hd + cc * ML_HC + t * 64 + c8 * 8) * 2) : FC_OOB;
-        const v4u hv = *(const v4u*)(smem + XB + lo);
-        __builtin_amdgcn_raw_buffer_store_b128(hv, rsAct, go, 0, 0);
-        if (!BWD) {
-          const v4u gv = *(const v4u*)(smem + GB + lo);
-          __builtin_amdgcn_raw_buffer_store_b128(gv, rsG, go, 0, 0);
-        }
-      }
-    };
-    ml_read_a(A0, xa0, xa1);                                                // piece 0: X image 0
+    ml_read_a(A0, xa0);                                                     // piece 0: X image 0
+    ml_read_a(A1, xa1);
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
       const int hsel = (c & 1) * 2 * ML_TILE;
       ML_STAMP(2 + 4 * c);
-      if (c > 0) store_images(c - 1);
       float4 bias[2];
       uint2 gp[4][2];
       if (!BWD) {
@@ -239,61 +260,100 @@ __global__ void __launch_bounds__(512) k_mlp_fused(const MlpArgs a) {
             gp[i][j] = *(uint2*)&v;
           }
       }
-#define ML_STEP_A(P, AC, AN)                                                                                   \
+#define ML_STEP_A(P)                                                                                           \
   {                                                                                                            \
     constexpr int PN = ((P) + 1) % NT1;                                                                        \
-    if (!ML_DBG(8)) ml_read_a(AN, xa0 + PN * ML_TILE, xa1 + PN * ML_TILE);                                     \
-    if (!ML_DBG(2)) ml_mfma(AC, Bq[(P) % ML_NBA], uacc);                                                       \
+    ml_mfma<0, true>(A0, Bq[(P) % ML_NBA], uacc, xa0 + PN * ML_TILE);                                          \
+    ml_mfma<1, true>(A1, Bq[(P) % ML_NBA], uacc, xa1 + PN * ML_TILE);                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (!ML_DBG(4)) ML_REFILL(P, ML_NBA, 0);                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
       static_assert(ND == 3, "the piece sequence below is written out for D = 384");
-      ML_STEP_A(0, A0, A1) ML_STEP_A(1, A1, A0) ML_STEP_A(2, A0, A1) ML_STEP_A(3, A1, A0) ML_STEP_A(4, A0, A1) ML_STEP_A(5, A1, A0)
+      ML_STEP_A(0) ML_STEP_A(1) ML_STEP_A(2) ML_STEP_A(3) ML_STEP_A(4) ML_STEP_A(5)
 #undef ML_STEP_A
       ML_STAMP(3 + 4 * c);
-      // ---- the activation: registers -> H image c & 1 (LDS) + global
+      ml_barrier_x();                     // phase boundary: the matrix pipe goes to the other role (second product of chunk c - 1) ...
+      // ---- ... while this one runs the activation on the VALU: registers -> H image c & 1 (and gelu' -> G image) in LDS; the other role
+      // stores the images to global memory during the next chunk's first phase
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        float hv[8], gv[8];
+        if (!BWD) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float bj[4] = {bias[j].x, bias[j].y, bias[j].z, bias[j].w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[4 * j + x] = uacc[i][j][x] + bj[x];
+          }
+          if (!ML_DBG(1)) ml_gelu<8>(v, hv, gv);
+          else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { hv[k] = v[k]; gv[k] = v[k]; }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const unsigned ga = gp[i][j].x, gb = gp[i][j].y;
+            hv[4 * j + 0] = uacc[i][j][0] * __uint_as_float(ga << 16); hv[4 * j + 1] = uacc[i][j][1] * __uint_as_float(ga & 0xffff0000u);
+            hv[4 * j + 2] = uacc[i][j][2] * __uint_as_float(gb << 16); hv[4 * j + 3] = uacc[i][j][3] * __uint_as_float(gb & 0xffff0000u);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          float hv[4];
           if (!BWD) {
-            const float bj[4] = {bias[j].x, bias[j].y, bias[j].z, bias[j].w};
-            float gv[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              const float v = uacc[i][j][x] + bj[x];
-              float cdf, pdf;
-              if (!ML_DBG(1)) gelu_fast_parts(v, cdf, pdf); else { cdf = v; pdf = v; }
-              gv[x] = cdf + v * pdf;
-              hv[x] = v * cdf;
-            }
-            uint2 gg = make_uint2(f2bf2(gv[0], gv[1]), f2bf2(gv[2], gv[3]));
+            uint2 gg = make_uint2(f2bf2(gv[4 * j], gv[4 * j + 1]), f2bf2(gv[4 * j + 2], gv[4 * j + 3]));
             *(uint2*)(smem + (GB - XB) + hoff[j] + hsel + i * 2048) = gg;
-          } else {
-            const unsigned ga = gp[i][j].x, gb = gp[i][j].y;
-            hv[0] = uacc[i][j][0] * __uint_as_float(ga << 16); hv[1] = uacc[i][j][1] * __uint_as_float(ga & 0xffff0000u);
-            hv[2] = uacc[i][j][2] * __uint_as_float(gb << 16); hv[3] = uacc[i][j][3] * __uint_as_float(gb & 0xffff0000u);
           }
-          uint2 hh = make_uint2(f2bf2(hv[0], hv[1]), f2bf2(hv[2], hv[3]));
+          uint2 hh = make_uint2(f2bf2(hv[4 * j], hv[4 * j + 1]), f2bf2(hv[4 * j + 2], hv[4 * j + 3]));
           *(uint2*)(smem + hoff[j] + hsel + i * 2048) = hh;
           uacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+      }
       ML_STAMP(4 + 4 * c);
       lds_barrier();                      // H image c & 1 is complete; the other role has finished reading image (c + 1) & 1 (chunk c - 1)
       ML_STAMP(5 + 4 * c);
     }
-    store_images(NCH - 1);
-    lds_barrier();                        // the other role's last chunk
+    ml_barrier_x();                       // the other role's last chunk: its stores, then its products
+    lds_barrier();
   } else {
     // ================================================== second product
+#pragma unroll
+    for (int k = 0; k < ML_NB; ++k) load_b(Bq[k], NT1 + k);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * ML_NB) : "memory");        // the X panel has landed (the weight loads are younger)
+    ML_STAMP(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ML_STAMP(1);
+    f32x4 yacc[ND][4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int nb = 0; nb < ND; ++nb) yacc[nb][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rsAct = make_store_rsrc((void*)a.act, (long)M * Hd * 2);
+    const __amdgpu_buffer_rsrc_t rsG = make_store_rsrc((void*)a.gsave, (long)M * Hd * 2);
+    // The activation leaves for global memory from THIS role (it has the slack: no activation arithmetic), row-wise out of the LDS images,
+    // behind the chunk's products: 16 lanes store one 256-byte row segment with 16-byte accesses.  (Stored straight from the accumulator layout -- 8 bytes per lane, 32-byte runs -- the sixteen dwordx2 stores per
+    // wave and chunk took 1.6 us per chunk at issue, 19 us of a 51-us launch: profiles/r05/mlp_fused_v4a_ablate.txt.)
+    auto store_images = [&](int cc) {
+      const int hs = (cc & 1) * 2 * ML_TILE;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int item = it * 256 + (tid - 256), c8 = item & 7, t = (item >> 3) & 1, rho = item >> 4;
+        const int lo = hs + t * ML_TILE + rho * 128 + ((c8 ^ ((rho >> 1) & 7)) << 4);
+        const unsigned go = (m0 + rho < M) ? (unsigned)(((m0 + rho) * Hd + cc * ML_HC + t * 64 + c8 * 8) * 2) : FC_OOB;
+        const v4u hv = *(const v4u*)(smem + XB + lo);
+        __builtin_amdgcn_raw_buffer_store_b128(hv, rsAct, go, 0, 0);
+        if (!BWD) {
+          const v4u gv = *(const v4u*)(smem + GB + lo);
+          __builtin_amdgcn_raw_buffer_store_b128(gv, rsG, go, 0, 0);
+        }
+      }
+    };
+    ml_barrier_x();
     lds_barrier();                        // H image 0 is complete
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
@@ -301,36 +361,42 @@ __global__ void __launch_bounds__(512) k_mlp_fused(const MlpArgs a) {
       ML_STAMP(2 + 4 * c);
       const char* ha0 = xa0 + hsel;
       const char* ha1 = xa1 + hsel;
-      ml_read_a(A0, ha0, ha1);                                              // piece 0 of the half chunk: H image 0
-#define ML_STEP_B(P, AC, AN)                                                                                   \
+      store_images(c);                    // phase 1 (the other role runs the first product of chunk c + 1 on the matrix pipe): chunk c's images -> global
+      ml_read_a(A0, ha0);                                                   // piece 0 of the half chunk: H image 0
+      ml_read_a(A1, ha1);
+      ML_STAMP(4 + 4 * c);
+      ml_barrier_x();                     // phase 2: the matrix pipe is this role's
+#define ML_STEP_B(P)                                                                                           \
   {                                                                                                            \
-    if ((P) + 1 < NT1 && !ML_DBG(8)) ml_read_a(AN, ha0 + (((P) + 1) & 1) * ML_TILE, ha1 + (((P) + 1) & 1) * ML_TILE); \
-    if (!ML_DBG(2)) ml_mfma(AC, Bq[(P) % ML_NB], yacc[(P) >> 1]);                                              \
+    ml_mfma<0, ((P) + 1 < NT1)>(A0, Bq[(P) % ML_NB], yacc[(P) >> 1], ha0 + (((P) + 1) & 1) * ML_TILE);         \
+    ml_mfma<1, ((P) + 1 < NT1)>(A1, Bq[(P) % ML_NB], yacc[(P) >> 1], ha1 + (((P) + 1) & 1) * ML_TILE);         \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (!ML_DBG(4)) ML_REFILL(P, ML_NB, 1);                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
-      ML_STEP_B(0, A0, A1) ML_STEP_B(1, A1, A0) ML_STEP_B(2, A0, A1) ML_STEP_B(3, A1, A0) ML_STEP_B(4, A0, A1) ML_STEP_B(5, A1, A0)
+      ML_STEP_B(0) ML_STEP_B(1) ML_STEP_B(2) ML_STEP_B(3) ML_STEP_B(4) ML_STEP_B(5)
 #undef ML_STEP_B
       ML_STAMP(3 + 4 * c);
       lds_barrier();                      // done with H image c & 1; image (c + 1) & 1 is complete
       ML_STAMP(5 + 4 * c);
     }
+    // every wave of the workgroup is past its last LDS read: y -> fp32 image [64][D + 4] over the LDS
+    {
+      float* Cw = (float*)smem;
+#pragma unroll
+      for (int nb = 0; nb < ND; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            *(float4*)(Cw + (16 * i + r) * (D + 4) + nb * 128 + 32 * w + 16 * j + 4 * g) = make_float4(yacc[nb][i][j][0], yacc[nb][i][j][1], yacc[nb][i][j][2], yacc[nb][i][j][3]);
+    }
   }
 #undef ML_REFILL
-  // ---- output: y (held by the second role) -> fp32 image [64][D + 4] over the LDS -> rows of 2 D bytes, by all 512 threads
+  // ---- output: the fp32 image [64][D + 4] over the LDS (written by the second role above) -> rows of 2 D bytes, by all 512 threads
   constexpr int CLD = D + 4;
-  float* Cs = (float*)smem;
+  const float* Cs = (const float*)smem;
   ML_STAMP(60);
-  if (role == 1) {
-#pragma unroll
-    for (int nb = 0; nb < ND; ++nb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          *(float4*)(Cs + (16 * i + r) * CLD + nb * 128 + 32 * w + 16 * j + 4 * g) = make_float4(yacc[nb][i][j][0], yacc[nb][i][j][1], yacc[nb][i][j][2], yacc[nb][i][j][3]);
-  }
   lds_barrier();
   constexpr int CG = D / 8;                                                  // 8-column groups per row
 #pragma unroll 2

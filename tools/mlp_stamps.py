@@ -31,5 +31,5 @@ for w in (0, 4):
     print(f"wave {w} ({'first product + activation' if w < 4 else 'second product'}): X landed at {s[0]-t0}, barrier passed {s[1]-t0}, output phase {s[60]-t0} .. {s[61]-t0}")
     for c in range(12):
         a, b, d, e = s[2 + 4 * c], s[3 + 4 * c], s[4 + 4 * c], s[5 + 4 * c]
-        if w < 4: print(f"   chunk {c:2d}: start {a-t0:7d} | stores + 6 pieces {b-a:6d} | activation {d-b:6d} | barrier wait {e-d:6d}")
-        else: print(f"   chunk {c:2d}: start {a-t0:7d} | 6 pieces {b-a:6d} | barrier wait {e-b:6d}")
+        if w < 4: print(f"   chunk {c:2d}: start {a-t0:7d} | 6 pieces {b-a:6d} | phase barrier + activation {d-b:6d} | barrier wait {e-d:6d}")
+        else: print(f"   chunk {c:2d}: start {a-t0:7d} | image stores + first reads {d-a:6d} | phase barrier + 6 pieces {b-d:6d} | barrier wait {e-b:6d}")
