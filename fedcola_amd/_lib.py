@@ -16,6 +16,7 @@ elif os.environ.get("FC_PROBES_LIB"):      # tools only: the -DFC_PROBES build w
 
 FC_PREC_FP32, FC_PREC_BF16 = 0, 1
 FC_TASK_NONE, FC_TASK_CLS, FC_TASK_RTV = 0, 1, 2
+FC_OPT_MLP_FUSED, FC_OPT_STEP_GRAPH, FC_OPT_GEMM_FORM = 1, 2, 3
 
 
 class FcModelCfg(C.Structure):
@@ -52,6 +53,7 @@ SIGNATURES = {
     "fc_model_num_segments": (_I, [_P]),
     "fc_model_segment": (C.c_int, [_P, _I, C.POINTER(FcSegment)]),
     "fc_model_set_trainable": (C.c_int, [_P, _I, _I]),
+    "fc_model_set_option": (C.c_int, [_P, _I, _I]),
     "fc_workspace_bytes": (_Z, [_P, _I, _I]),
     "fc_compute_weights_bytes": (_Z, [_P]),
     "fc_prepare_weights": (C.c_int, [_P, _P, _P, _P]),

@@ -107,7 +107,7 @@ class FedavgClient(BaseClient):
         started = None
         if dev.type == "cuda" and getattr(self.args, "prefetch", True) and self.args.E > 0:
             from ..loaders.prefetch import DevicePrefetcher       # H2D of the next batches on a copy stream (N4)
-            started = DevicePrefetcher(self.train_loader, dev, depth=2, stream=model.side_stream()).start()
+            started = DevicePrefetcher(self.train_loader, dev, depth=2, stream=model.side_stream(), device_ring=self._device_ring()).start()
         n = model.flat.numel()
         grads = torch.zeros(n, device=dev)
         exp_avg = torch.zeros(n, device=dev)        # optimizer re-created every round: fresh state (fedavgclient.py:63)
@@ -133,8 +133,15 @@ class FedavgClient(BaseClient):
                 loader, started = started, None
             elif dev.type == "cuda" and getattr(self.args, "prefetch", True):
                 from ..loaders.prefetch import DevicePrefetcher
-                loader = DevicePrefetcher(self.train_loader, dev, depth=2, stream=model.side_stream())
+                loader = DevicePrefetcher(self.train_loader, dev, depth=2, stream=model.side_stream(), device_ring=self._device_ring())
+            raw_finish = getattr(self.train_loader, "device_finish", None)
             for batch in loader:
+                if raw_finish is not None and torch.is_tensor(batch[0]) and batch[0].dtype == torch.uint8:
+                    # a raw (uint8 image code) loader without the prefetcher in front of it (args.prefetch switched off after construction,
+                    # a non-cuda device): expand here -- the codes must never reach `.float()` below as if they were pixels
+                    batch = list(batch)
+                    batch[0] = batch[0].to(dev, non_blocking=True)
+                    batch = raw_finish(batch)
                 if num >= 2 and self.args.debug:                       # fedavgclient.py:73-75
                     mm.add_loss_sum(lossbuf[0].clone())
                     mm.aggregate(num * self.args.B, e + 1)
@@ -197,6 +204,14 @@ class FedavgClient(BaseClient):
             step = self._after_epoch(e, st, step)
         # the reference moves the model back to the CPU here (fedavgclient.py:114); weights stay resident in HBM instead
         return mm.results
+
+    def _device_ring(self):
+        """The fixed device buffers the prefetcher copies this client's batches into (three per position): the same addresses step after
+        step and round after round, which is what lets fc_client_step replay its captured graphs."""
+        ring = getattr(self, "_dev_ring", None)
+        if ring is None:
+            ring = self._dev_ring = {}
+        return ring
 
     def _update_unfused(self, mm, oargs, prox=None):
         """Any torch optimizer / gradient clipping: HIP forward+backward through autograd, torch.optim on the flat views."""

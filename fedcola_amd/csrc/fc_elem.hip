@@ -778,7 +778,8 @@ FcAdamW fc_adamw_consts(float lr, float beta1, float beta2, float eps, float wd,
   return o;
 }
 // one workgroup per chunk; float4 accesses where the chunk is 16-B aligned (every tensor of the models here is), scalar otherwise
-__global__ void __launch_bounds__(256) k_adamw_chunks(const FcProxChunk* __restrict__ chunks, FcAdamW o) {
+__global__ void __launch_bounds__(256) k_adamw_chunks(const FcProxChunk* __restrict__ chunks, FcAdamW o_) {
+  const FcAdamW o = fc_adamw_resolve(o_);
   const FcProxChunk c = chunks[blockIdx.x];
   float* p = o.p + c.offset; float* g = o.g0 + c.offset; float* m = o.m + c.offset; float* v = o.v + c.offset;
   if (((c.offset | c.n) & 3) == 0) {
@@ -809,6 +810,12 @@ __global__ void __launch_bounds__(256) k_add_chunks(float* __restrict__ dst, con
 int fc_add_chunks(float* dst, const float* src, const FcProxChunk* chunks_dev, int nchunks, hipStream_t s) {
   if (nchunks <= 0) return 0;
   hipLaunchKernelGGL(k_add_chunks, dim3(nchunks), dim3(256), 0, s, dst, src, chunks_dev);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void k_adamw_set_dyn(float* dyn, float decay, float step_size, float inv_bc2_sqrt) { dyn[0] = decay; dyn[1] = step_size; dyn[2] = inv_bc2_sqrt; }
+int fc_adamw_set_dyn(float* dyn_dev, const FcAdamW& o, hipStream_t s) {
+  hipLaunchKernelGGL(k_adamw_set_dyn, dim3(1), dim3(1), 0, s, dyn_dev, o.decay, o.step_size, o.inv_bc2_sqrt);
   FC_LAUNCH_CHECK();
   return 0;
 }

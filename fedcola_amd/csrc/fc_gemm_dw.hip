@@ -142,7 +142,8 @@ __device__ __forceinline__ void dw_tile(unsigned lb, unsigned po, const DwKeys& 
 }
 
 template <bool OPT>
-__global__ void __launch_bounds__(512, 2) k_gemm_dw_wide(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o) {
+__global__ void __launch_bounds__(512, 2) k_gemm_dw_wide(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o_) {
+  const FcAdamW o = fc_adamw_resolve(o_);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -325,7 +326,8 @@ __device__ __forceinline__ void dws_kstep(unsigned lb, unsigned po, const DwKeys
 
 #define DWS_SLOT 32768   // one stage: 4 images of [32 k][128 cols]
 template <bool OPT>
-__global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o) {
+__global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o_) {
+  const FcAdamW o = fc_adamw_resolve(o_);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 8;

@@ -90,9 +90,17 @@ struct FcAdamW {
   float* v = nullptr;          // exp_avg_sq
   bf16_t* shadow = nullptr;    // bf16 compute weights for the next step (may be null)
   float decay, beta1, beta2, eps, step_size, inv_bc2_sqrt;
+  // non-null: {decay, step_size, inv_bc2_sqrt} are read from this device array instead (a captured step graph bakes its kernel arguments in;
+  // the three values that change from step to step are written there ahead of every replay: fc_adamw_set_dyn)
+  const float* dyn = nullptr;
 };
+int fc_adamw_set_dyn(float* dyn_dev, const FcAdamW& o, hipStream_t s);
 FcAdamW fc_adamw_consts(float lr, float beta1, float beta2, float eps, float wd, int step);
 #ifdef __HIPCC__
+__device__ __forceinline__ FcAdamW fc_adamw_resolve(FcAdamW o) {
+  if (o.dyn) { o.decay = o.dyn[0]; o.step_size = o.dyn[1]; o.inv_bc2_sqrt = o.dyn[2]; }
+  return o;
+}
 __device__ __forceinline__ void fc_adamw_elem(float& p, float g, float& m, float& v, float decay, float beta1, float beta2, float eps, float step_size,
                                               float inv_bc2_sqrt) {
 #pragma clang fp contract(off)   // every product and sum rounded on its own, wherever this is inlined: the same bits from every kernel
@@ -158,6 +166,7 @@ int fc_dw_x3(const float* dY, const float* X, float* dW, float* db, int rows, in
 struct GemmProb { const bf16_t* A; const bf16_t* B; void* C; long lda, ldb, ldc; int M; GemmEpi e; };
 struct GemmGroup { GemmProb p[2]; int N, K, tiles_n, tiles0, ntiles; };
 int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t s);
+void fc_gemm_set_form(int form);      // process-wide: 0 | 64 | 3 | 4 (fc_mfma.hip)
 
 // ---- fused MLP (fc_mlp.hip): fc1 -> GELU -> fc2 per 64-row panel, or its backward mirror; D = 384 only.  The weights come from streams packed
 // in MFMA-fragment order (fc_mlp_pack: one launch for a table of {W1, W2, forward stream, backward stream} jobs, fc_mlp_pack_elems bf16 each).

@@ -170,8 +170,8 @@ enum { EPI_PLAIN = 0, EPI_BIAS, EPI_RES, EPI_RES_SCALE, EPI_GELU, EPI_GELU_GRAD,
 // (conflict-free for the accumulator writes -- 8 lanes, 8 rows, one column slot -- and for the row reads).
 __device__ __forceinline__ int cs_slot(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 2); }
 // half hp of the tile = rows {64 wm + 32 hp + r, r < 32}: image row = 32 wm + r, every wave contributes two row-fragments
-template <int HP>
-__device__ __forceinline__ void acc_to_lds_half(float* Cs, const f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+template <int HP, int NI>
+__device__ __forceinline__ void acc_to_lds_half(float* Cs, const f32x4 (&acc)[NI][4], int wm, int wn, int lane) {
   const int g = lane >> 4, cl = lane & 15;
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
@@ -181,7 +181,7 @@ __device__ __forceinline__ void acc_to_lds_half(float* Cs, const f32x4 (&acc)[4]
           make_float4(acc[2 * HP + ii][j][0], acc[2 * HP + ii][j][1], acc[2 * HP + ii][j][2], acc[2 * HP + ii][j][3]);
 }
 // store instructions one thread issues per output tile with the compile-time epilogues (0: unknown -> full drain)
-template <int EPI, typename TC> struct EpiStores { static constexpr int n = EPI == EPI_GENERIC ? 0 : ((EPI == EPI_GELU || EPI == EPI_GELU_SG) ? 16 : 8) * (sizeof(TC) == 2 ? 1 : 2); };
+template <int EPI, typename TC, int MT = 128> struct EpiStores { static constexpr int n = EPI == EPI_GENERIC ? 0 : ((EPI == EPI_GELU || EPI == EPI_GELU_SG) ? 16 : 8) * (sizeof(TC) == 2 ? 1 : 2) * MT / 128; };
 // Global inputs of a tile's epilogue (bias, residual / GELU' operand, drop-path scale), requested for BOTH halves before the
 // tile's last k-step: vmcnt retires in order, so a load issued after a store cannot be waited for without also waiting
 // out that store's write latency -- loading inside each half serialised every half behind the previous half's stores.
@@ -189,8 +189,8 @@ struct EpiRegs { float bias[8]; uint4 rin0[4], rin1[4]; float sc0[4], sc1[4]; };
 template <int EPI, typename TC> struct EpiPre {
   static constexpr bool on = sizeof(TC) == 2 && EPI != EPI_GENERIC && EPI != EPI_PATCH;
 };
-#define TILE_ROW2(row, hp) ((((row) >> 5) << 6) + (hp) * 32 + ((row) & 31))
-template <int EPI, typename TC>
+#define TILE_ROW2(row, hp) (MT == 64 ? (row) : ((((row) >> 5) << 6) + (hp) * 32 + ((row) & 31)))
+template <int EPI, typename TC, int MT = 128>
 __device__ __forceinline__ void epi_prefetch(EpiRegs& R, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid) {
   constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_RES || EPI == EPI_RES_SCALE || EPI == EPI_GELU || EPI == EPI_GELU_SG;
   constexpr bool HAS_RES = EPI == EPI_RES || EPI == EPI_RES_SCALE;
@@ -204,19 +204,19 @@ __device__ __forceinline__ void epi_prefetch(EpiRegs& R, long ldc, int m0, int n
       const int ma = m0 + TILE_ROW2(r0 + 16 * q, 0), mb = m0 + TILE_ROW2(r0 + 16 * q, 1);
       const int mca = ma < M ? ma : M - 1, mcb = mb < M ? mb : M - 1;
       const size_t offa = (size_t)mca * ldc + nc, offb = (size_t)mcb * ldc + nc;
-      if (HAS_RES) { R.rin0[q] = *(const uint4*)((const bf16_t*)e.res + offa); R.rin1[q] = *(const uint4*)((const bf16_t*)e.res + offb); }
-      if (HAS_IN) { R.rin0[q] = *(const uint4*)((const bf16_t*)e.gelu_in + offa); R.rin1[q] = *(const uint4*)((const bf16_t*)e.gelu_in + offb); }
-      if (EPI == EPI_RES_SCALE) { R.sc0[q] = e.rowscale[mca / e.rows_per_sample]; R.sc1[q] = e.rowscale[mcb / e.rows_per_sample]; }
+      if (HAS_RES) { R.rin0[q] = *(const uint4*)((const bf16_t*)e.res + offa); if (MT == 128) R.rin1[q] = *(const uint4*)((const bf16_t*)e.res + offb); }
+      if (HAS_IN) { R.rin0[q] = *(const uint4*)((const bf16_t*)e.gelu_in + offa); if (MT == 128) R.rin1[q] = *(const uint4*)((const bf16_t*)e.gelu_in + offb); }
+      if (EPI == EPI_RES_SCALE) { R.sc0[q] = e.rowscale[mca / e.rows_per_sample]; if (MT == 128) R.sc1[q] = e.rowscale[mcb / e.rows_per_sample]; }
     }
   }
 }
 // one half (64 rows starting at tile row `rbase`) of the fused epilogue; thread owns columns 8*(tid&15).. and rows (tid>>4) + 16q
-template <int EPI, typename TC, bool PRE = false>
+template <int EPI, typename TC, bool PRE = false, int MT = 128>
 __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, int m0, int n0, int M, int N, const GemmEpi& e, int tid, int hp,
                                               __amdgpu_buffer_rsrc_t crs, __amdgpu_buffer_rsrc_t prs, const float (&pbias)[8],
                                               const uint4 (&prin)[4], const float (&psc)[4]) {
   const int c8 = (tid & 15) * 8, n = n0 + c8, r0 = tid >> 4;
-#define TILE_ROW(row) ((((row) >> 5) << 6) + hp * 32 + ((row) & 31))   /* image row -> row inside the 128-row tile */
+#define TILE_ROW(row) (MT == 64 ? (row) : ((((row) >> 5) << 6) + hp * 32 + ((row) & 31)))   /* image row -> row inside the tile */
   if (EPI == EPI_GENERIC) {
     if (n >= N) return;
 #pragma unroll 1
@@ -329,7 +329,7 @@ __device__ __forceinline__ void half_epilogue(const float* Cs, TC* C, long ldc, 
   const float b[8] = {};
   const uint4 r[4] = {};
   const float c[4] = {};
-  half_epilogue<EPI, TC, false>(Cs, C, ldc, m0, n0, M, N, e, tid, hp, crs, prs, b, r, c);
+  half_epilogue<EPI, TC, false, 128>(Cs, C, ldc, m0, n0, M, N, e, tid, hp, crs, prs, b, r, c);
 }
 
 // ---- main loop shared by the single-problem and the grouped kernels.
@@ -356,21 +356,22 @@ __device__ __forceinline__ void tile_store(const StageRegs& R, char* buf, int ti
     }
   }
 }
-template <int AMODE, int BMODE>
-__device__ __forceinline__ void tile_compute(const char* buf, f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+// NI = row blocks of 16 per wave: 4 (128-row tile) or 2 (64-row tile: a wave's rows start at 32 wm)
+template <int AMODE, int BMODE, int NI = 4>
+__device__ __forceinline__ void tile_compute(const char* buf, f32x4 (&acc)[NI][4], int wm, int wn, int lane) {
   const char* la = buf;
   const char* lb = buf + 16384;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 af[4], bfr[4];
+    bf16x8 af[NI], bfr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = frag_read<AMODE>(la, wm * 64 + i * 16, ks, lane);
+    for (int i = 0; i < NI; ++i) af[i] = frag_read<AMODE>(la, wm * (16 * NI) + i * 16, ks, lane);
 #pragma unroll
     for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BMODE>(lb, wn * 64 + j * 16, ks, lane);
-    if (AMODE == KR) frag_fence(af);
+    if (AMODE == KR) { static_assert(AMODE != KR || NI == 4, "KR A operand: 128-row tiles only"); frag_fence(*(bf16x8(*)[4])&af); }
     if (BMODE == KR) frag_fence(bfr);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
   }
@@ -411,7 +412,10 @@ __device__ __forceinline__ void gemm_mainloop(const bf16_t* __restrict__ A, long
 // Operand tiles stream global -> LDS directly (LDS-DMA), double-buffered: the loads of k-tile t+1 (or of the NEXT output tile's
 // first k-tile) are in flight while k-tile t feeds the MFMAs and while the epilogue runs.  One barrier per k-tile: wait for own DMA
 // (vmcnt) -> barrier -> issue next DMA -> compute.
-template <int AMODE, int BMODE, typename TC, int EPI>
+// MT: rows of an output tile.  128 (default) or 64: launches whose 128-row tiles would leave most of the chip idle (a 4 334-row chain with N = 384:
+// 102 tiles on 256 CUs, every workgroup walking K = 1 536 alone) are cut into twice as many 64 x 128 tiles -- what the vendor library's
+// heuristic does on these shapes (MT128x64, profiles/r05/vendor_yardstick_*.txt: 18.2 against 23.5 us on 4 334 x 384 x 1 536).
+template <int AMODE, int BMODE, typename TC, int EPI, int MT = 128>
 __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A 16 KB | B 16 KB) + a separate epilogue image
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -420,9 +424,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
   const int first = xcd_remap(blockIdx.x, G);
   const int N = g.N, K = g.K, tiles_n = g.tiles_n, ntiles = g.ntiles;
   const int T = (K + BK - 1) / BK;
-  f32x4 acc[4][4];
+  constexpr int NI = MT / 32, NPA = MT / 32;      // row blocks per wave; 1-KB pieces of the A tile per wave
+  static_assert(MT == 128 || (MT == 64 && AMODE == KC), "64-row tiles: k-contiguous A operand only");
+  f32x4 acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // load side: tile `lt` (of problem `lprob`), k-tile `lk`, destination buffer parity `lb`
@@ -439,14 +445,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
       lprob = pr;
     }
     const int l = t - (pr ? g.tiles0 : 0);
-    retarget_glds<AMODE>(oa, P.lda, (l / tiles_n) * BM, P.M, wave, lane, valid);
+    retarget_glds<AMODE, NPA>(oa, P.lda, (l / tiles_n) * MT, P.M, wave, lane, valid);
     retarget_glds<BMODE>(ob, P.ldb, (l % tiles_n) * BN, N, wave, lane, valid);
   };
   retarget();
 #define ISSUE_NEXT()                                                                   \
   do {                                                                                 \
     char* dst = smem + lb * 32768;                                                     \
-    stage_glds<AMODE>(oa, dst, lk * BK, K, wave, lane);                                \
+    stage_glds<AMODE, NPA>(oa, dst, lk * BK, K, wave, lane);                           \
     stage_glds<BMODE>(ob, dst + 16384, lk * BK, K, wave, lane);                        \
     lb ^= 1;                                                                           \
     if (++lk == T) {                                                                   \
@@ -457,7 +463,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
   } while (0)
   ISSUE_NEXT();                      // k-tile 0 of the first tile -> buffer 0
   int cb = 0;                        // buffer holding the k-tile to compute next
-  constexpr int NST = EpiStores<EPI, TC>::n;
+  constexpr int NST = EpiStores<EPI, TC, MT>::n;
   EpiRegs pre;
   for (int ct = first; ct < ntiles; ct += G) {
     const int pr = ct >= g.tiles0;
@@ -467,7 +473,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
     const long ldc = P.ldc;
     TC* C = (TC*)P.C;
     const int lct = ct - (pr ? g.tiles0 : 0);
-    const int m0 = (lct / tiles_n) * BM, n0 = (lct % tiles_n) * BN;
+    const int m0 = (lct / tiles_n) * MT, n0 = (lct % tiles_n) * BN;
     for (int k = 0; k < T; ++k) {
       // this wave's pieces of the current k-tile have landed.  Right after an epilogue the youngest NST operations are that
       // epilogue's stores (a fixed count per thread): skip them instead of draining the HBM write latency.
@@ -476,8 +482,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
       __builtin_amdgcn_s_barrier();                        // ... everyone's have, and the other buffer is no longer being read
       asm volatile("" ::: "memory");
       ISSUE_NEXT();                                        // next k-tile (possibly of the next output tile) -> other buffer
-      if (EpiPre<EPI, TC>::on && k == T - 1) epi_prefetch<EPI, TC>(pre, ldc, m0, n0, M, N, e, tid);   // lands under the last MFMAs
-      tile_compute<AMODE, BMODE>(smem + cb * 32768, acc, wm, wn, lane);
+      if (EpiPre<EPI, TC>::on && k == T - 1) epi_prefetch<EPI, TC, MT>(pre, ldc, m0, n0, M, N, e, tid);   // lands under the last MFMAs
+      tile_compute<AMODE, BMODE, NI>(smem + cb * 32768, acc, wm, wn, lane);
       cb ^= 1;
     }
     // ---- epilogue, two 64-row halves through the staging buffer that was computed last (the other one is receiving the
@@ -487,15 +493,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
     const __amdgpu_buffer_rsrc_t prs = make_store_rsrc(e.preact ? e.preact : (void*)C, crows * ldc * (long)sizeof(TC));
     float* Cs = (float*)(smem + (cb ^ 1) * 32768);
     lds_barrier();                                         // last MFMA fragment reads of this buffer are done
-    acc_to_lds_half<0>(Cs, acc, wm, wn, lane);
+    acc_to_lds_half<0, NI>(Cs, acc, wm, wn, lane);
     lds_barrier();
-    half_epilogue<EPI, TC, true>(Cs, C, ldc, m0, n0, M, N, e, tid, 0, crs, prs, pre.bias, pre.rin0, pre.sc0);
-    lds_barrier();
-    acc_to_lds_half<1>(Cs, acc, wm, wn, lane);
-    lds_barrier();
-    half_epilogue<EPI, TC, true>(Cs, C, ldc, m0, n0, M, N, e, tid, 1, crs, prs, pre.bias, pre.rin1, pre.sc1);
+    half_epilogue<EPI, TC, true, MT>(Cs, C, ldc, m0, n0, M, N, e, tid, 0, crs, prs, pre.bias, pre.rin0, pre.sc0);
+    if (MT == 128) {
+      lds_barrier();
+      acc_to_lds_half<(MT == 128 ? 1 : 0), NI>(Cs, acc, wm, wn, lane);
+      lds_barrier();
+      half_epilogue<EPI, TC, true, MT>(Cs, C, ldc, m0, n0, M, N, e, tid, 1, crs, prs, pre.bias, pre.rin1, pre.sc1);
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     lds_barrier();                                         // image reads done before the next DMA may target this buffer
@@ -505,6 +513,87 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
 }
 
 
+// ======================================================================== 64 x 128 tiles, one per workgroup, deep staging ring
+// The launches this is for: a chain's N = 384 products with a long reduction (fc2 forward, fc1 dX: K = 1 536; qkv dX: K = 1 152) at
+// 4 334 rows -- 102 tiles of 128 x 128, one workgroup alone on each of 102 CUs walking 18-24 k-steps, each k-step waiting out a whole
+// L2 / HBM round trip (one k-tile in flight): 24.4 us, the longest kernels of a layer, where the vendor library's 128 x 64 tiles take
+// 18.2 / 15.8 us (profiles/r05/vendor_yardstick_*.txt).  Here: twice as many tiles (64 rows), NS stages of 24 KB (A 8 KB | B 16 KB) with
+// NS - 1 k-tiles in flight behind a counted vmcnt, one tile per workgroup (no cross-tile bookkeeping), 72-96 KB of LDS so that a 64-KB
+// workgroup of another chain still fits beside it (the 128-KB four-stage form of round 4 shut the other chains out and lost in the step).
+template <int BMODE, typename TC, int EPI, int NS>
+__global__ void __launch_bounds__(256, 1) k_gemm_d64(GemmGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // NS x (A [64][64] 8 KB | B 16 KB); the 32-KB epilogue image aliases it
+  constexpr int MT = 64, NI = 2, SLOT = 24576;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int N = g.N, K = g.K, tiles_n = g.tiles_n;
+  const int T = (K + BK - 1) / BK;
+  const int ct = xcd_remap(blockIdx.x, gridDim.x);
+  const int pr = ct >= g.tiles0;
+  const GemmProb& P = g.p[pr];
+  const GemmEpi& e = P.e;
+  const int M = P.M;
+  const long ldc = P.ldc;
+  TC* C = (TC*)P.C;
+  const int lct = ct - (pr ? g.tiles0 : 0);
+  const int m0 = (lct / tiles_n) * MT, n0 = (lct % tiles_n) * BN;
+  f32x4 acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Operand oa = make_operand_glds<KC>(P.A, P.lda, 0, M, K, wave, lane);
+  Operand ob = make_operand_glds<BMODE>(P.B, P.ldb, 0, N, K, wave, lane);
+  retarget_glds<KC, 2>(oa, P.lda, m0, M, wave, lane, true);
+  retarget_glds<BMODE>(ob, P.ldb, n0, N, wave, lane, true);
+  // k-tiles past the end fall outside the descriptors (zeros into a stage nobody reads again): every wave issues 6 DMAs per step, so the
+  // counted wait is the same immediate from the first step to the last
+#define D64_ISSUE(kt)                                                                  \
+  do {                                                                                 \
+    char* dst = smem + ((kt) % NS) * SLOT;                                             \
+    stage_glds<KC, 2>(oa, dst, (kt) * BK, K, wave, lane);                              \
+    stage_glds<BMODE>(ob, dst + 8192, (kt) * BK, K, wave, lane);                       \
+  } while (0)
+#pragma unroll 1
+  for (int d = 0; d < NS - 1; ++d) D64_ISSUE(d);
+  EpiRegs pre;
+  const int kpre = T >= 2 ? T - 2 : 0;
+#pragma unroll 1
+  for (int k = 0; k < T; ++k) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (NS - 2)) : "memory");      // this wave's pieces of k-tile k have landed; NS - 2 younger k-tiles stay in flight
+    __builtin_amdgcn_s_barrier();                                            // ... everyone's have, and the stage computed last is free again
+    asm volatile("" ::: "memory");
+    D64_ISSUE(k + NS - 1);
+    if (EpiPre<EPI, TC>::on && k == kpre) epi_prefetch<EPI, TC, MT>(pre, ldc, m0, n0, M, N, e, tid);
+    {
+      const char* buf = smem + (k % NS) * SLOT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[NI], bfr[4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) af[i] = frag_read<KC>(buf, wm * 32 + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BMODE>(buf + 8192, wn * 64 + j * 16, ks, lane);
+        if (BMODE == KR) frag_fence(bfr);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+#undef D64_ISSUE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the over-issued (all-zero) k-tiles land before the image reuses the ring
+  const long crows = (long)M + (e.patch_rows > 0 ? M / e.patch_rows + 2 : 0);
+  const __amdgpu_buffer_rsrc_t crs = make_store_rsrc((void*)C, crows * ldc * (long)sizeof(TC));
+  const __amdgpu_buffer_rsrc_t prs = make_store_rsrc(e.preact ? e.preact : (void*)C, crows * ldc * (long)sizeof(TC));
+  float* Cs = (float*)smem;
+  lds_barrier();
+  acc_to_lds_half<0, NI>(Cs, acc, wm, wn, lane);
+  lds_barrier();
+  half_epilogue<EPI, TC, true, MT>(Cs, C, ldc, m0, n0, M, N, e, tid, 0, crs, prs, pre.bias, pre.rin0, pre.sc0);
+}
+
 // ======================================================================== grouped weight-gradient GEMM
 // All dW = dY^T . X products of a backward pass (every linear of every layer of both towers) in ONE launch, each output
 // tile owned by exactly one workgroup that walks the whole reduction: no split-K, no atomics, bitwise reproducible.
@@ -513,7 +602,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
 // offsets as the gradient): the optimizer's pass over the linears' weights -- 86 % of the parameters, 7 HBM streams -- disappears into
 // the weight-gradient launches that run under the backward.
 template <bool OPT>
-__global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o) {
+__global__ void __launch_bounds__(256, 2) k_gemm_tn_grouped(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o_) {
+  const FcAdamW o = fc_adamw_resolve(o_);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -629,10 +719,10 @@ int fc_gemm_tn_grouped(const FcTnProblem* probs_dev, int nprob, int total_tiles,
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-template <int AM, int BMo, typename TC, int EPI>
+template <int AM, int BMo, typename TC, int EPI, int MT = 128>
 static int launch_gemm_epi(const GemmGroup& g, hipStream_t s) {
   const int lds = 65536;  // two 32-KB staging buffers; the epilogue image aliases the idle one
-  auto kfn = k_gemm_mfma<AM, BMo, TC, EPI>;
+  auto kfn = k_gemm_mfma<AM, BMo, TC, EPI, MT>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -668,18 +758,61 @@ static int epi_kind(const GemmEpi& e) {
 }
 // the epilogue kinds each GEMM form is instantiated for (anything else takes the run-time-flag EPI_GENERIC body)
 template <int AM, int BMo, typename TC>
-static int launch_gemm(const GemmGroup& g, int k, hipStream_t s) {
+static int launch_gemm(const GemmGroup& g, int k, hipStream_t s, bool mt64 = false) {
 #define GO(E) return launch_gemm_epi<AM, BMo, TC, E>(g, s)
+#define GO64(E) return launch_gemm_epi<AM, BMo, TC, E, 64>(g, s)
   if (AM == KC && BMo == KC && sizeof(TC) == 2) {   // forward linears
+    if constexpr (AM == KC && BMo == KC && sizeof(TC) == 2) {
+      if (mt64) switch (k) { case EPI_BIAS: GO64(EPI_BIAS); case EPI_RES: GO64(EPI_RES); case EPI_RES_SCALE: GO64(EPI_RES_SCALE); }
+    }
     switch (k) { case EPI_BIAS: GO(EPI_BIAS); case EPI_RES: GO(EPI_RES); case EPI_RES_SCALE: GO(EPI_RES_SCALE); case EPI_GELU: GO(EPI_GELU);
                  case EPI_PATCH: GO(EPI_PATCH); case EPI_PLAIN: GO(EPI_PLAIN); case EPI_GELU_SG: GO(EPI_GELU_SG); }
   } else if (AM == KC && BMo == KR && sizeof(TC) == 2) {   // dX
+    if constexpr (AM == KC && BMo == KR && sizeof(TC) == 2) {
+      if (mt64 && k == EPI_PLAIN) GO64(EPI_PLAIN);
+    }
     switch (k) { case EPI_PLAIN: GO(EPI_PLAIN); case EPI_GELU_GRAD: GO(EPI_GELU_GRAD); case EPI_BIAS: GO(EPI_BIAS); case EPI_MUL: GO(EPI_MUL); }
   } else {
     switch (k) { case EPI_PLAIN: GO(EPI_PLAIN); case EPI_BIAS: GO(EPI_BIAS); }
   }
   GO(EPI_GENERIC);
 #undef GO
+#undef GO64
+}
+template <int BMo, typename TC, int EPI, int NS>
+static int launch_gemm_d64(const GemmGroup& g, hipStream_t s) {
+  const int lds = NS * 24576;
+  auto kfn = k_gemm_d64<BMo, TC, EPI, NS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(g.ntiles), dim3(256), lds, s, g);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+// the deep 64-row form: bf16, long reductions, the epilogues of the model's N = 384 products.  Returns 1 when it has no such instantiation.
+static int launch_gemm_deep(int kind, int ek, int stages, const GemmGroup& g, hipStream_t s) {
+#define GO_D(BMo, E) return stages == 3 ? launch_gemm_d64<BMo, bf16_t, E, 3>(g, s) : launch_gemm_d64<BMo, bf16_t, E, 4>(g, s)
+  if (kind == FC_GEMM_NT) {
+    switch (ek) { case EPI_RES: GO_D(KC, EPI_RES); case EPI_RES_SCALE: GO_D(KC, EPI_RES_SCALE); case EPI_BIAS: GO_D(KC, EPI_BIAS); }
+  } else if (kind == FC_GEMM_NN) {
+    if (ek == EPI_PLAIN) GO_D(KR, EPI_PLAIN);
+  }
+#undef GO_D
+  return 1;
+}
+// process-wide form of the under-filled launches (fc_model_set_option FC_OPT_GEMM_FORM; tools build: FC_GEMM_MT64 / FC_GEMM_DEEP64):
+// 0 = 128-row tiles, 64 = 64-row tiles, 3 / 4 = 64-row tiles with a 3- / 4-stage ring
+static int g_gemm_form = 0;
+void fc_gemm_set_form(int form) { g_gemm_form = form; }
+// 64-row tiles exist for these (kind, output type, epilogue) combinations
+static bool gemm_has_mt64(int kind, int dtC, int ek) {
+  if (dtC != FC_BF16) return false;
+  if (kind == FC_GEMM_NT) return ek == EPI_BIAS || ek == EPI_RES || ek == EPI_RES_SCALE;
+  if (kind == FC_GEMM_NN) return ek == EPI_PLAIN;
+  return false;
 }
 
 static int gemm_prob_ok(int kind, const GemmProb& p, int N, int K) {
@@ -710,15 +843,39 @@ int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t 
 #endif
   }
   g.tiles_n = fc_cdiv(g.N, BN);
-  g.tiles0 = fc_cdiv(g.p[0].M, BM) * g.tiles_n;
-  g.ntiles = g.tiles0 + (nprob > 1 ? fc_cdiv(g.p[1].M, BM) * g.tiles_n : 0);
+  int mt = BM;
+  {
+    // a launch whose 128-row tiles would occupy less than about half of the chip's workgroup slots is cut into 64-row tiles instead
+    static const int thr_env = fc_knob("FC_GEMM_MT64", 0);      // (measured: 23.4 / 21.3 against 24.4 / 25.0 us stand-alone, +1 % in the step: off)
+    const int thr = thr_env > 0 ? thr_env : (g_gemm_form == 64 ? 128 : 0);
+    int t128 = 0;
+    for (int i = 0; i < nprob; ++i) t128 += fc_cdiv(g.p[i].M, BM) * g.tiles_n;
+    if (thr > 0 && t128 <= thr && gemm_has_mt64(kind, dtC, ek)) mt = 64;
+  }
+  {
+    // ... and when its reduction is long (K >= 1 024: fc2 forward, fc1 / qkv dX of a chain) into 64-row tiles with a deep staging ring, one per workgroup
+    static const int deep_env = fc_knob("FC_GEMM_DEEP64", 0);      // stages (3 | 4), 0 = off (stand-alone 24.4 -> 15.2 us, in the step +2 ... +6 %: off)
+    const int deep = deep_env >= 3 ? deep_env : ((g_gemm_form == 3 || g_gemm_form == 4) ? g_gemm_form : 0);
+    int t128 = 0;
+    for (int i = 0; i < nprob; ++i) t128 += fc_cdiv(g.p[i].M, BM) * g.tiles_n;
+    if (deep >= 3 && dtC == FC_BF16 && t128 <= 128 && g.K >= 1024 && (g.K % BK) == 0 && gemm_has_mt64(kind, dtC, ek)) {
+      GemmGroup d = g;
+      d.tiles0 = fc_cdiv(d.p[0].M, 64) * d.tiles_n;
+      d.ntiles = d.tiles0 + (nprob > 1 ? fc_cdiv(d.p[1].M, 64) * d.tiles_n : 0);
+      if (nprob == 1) d.p[1] = d.p[0];
+      const int r = launch_gemm_deep(kind, ek, deep, d, s);
+      if (r <= 0) return r;
+    }
+  }
+  g.tiles0 = fc_cdiv(g.p[0].M, mt) * g.tiles_n;
+  g.ntiles = g.tiles0 + (nprob > 1 ? fc_cdiv(g.p[1].M, mt) * g.tiles_n : 0);
   if (nprob == 1) g.p[1] = g.p[0];
   if (kind == FC_GEMM_NT) {
-    if (dtC == FC_BF16) return launch_gemm<KC, KC, bf16_t>(g, ek, s);
+    if (dtC == FC_BF16) return launch_gemm<KC, KC, bf16_t>(g, ek, s, mt == 64);
     return launch_gemm<KC, KC, float>(g, ek, s);
   }
   if (kind == FC_GEMM_NN) {
-    if (dtC == FC_BF16) return launch_gemm<KC, KR, bf16_t>(g, ek, s);
+    if (dtC == FC_BF16) return launch_gemm<KC, KR, bf16_t>(g, ek, s, mt == 64);
     return launch_gemm<KC, KR, float>(g, ek, s);
   }
   // TN (weight gradients normally go through fc_gemm_tn_grouped instead)

@@ -112,11 +112,12 @@ __device__ __forceinline__ Operand make_operand_glds(const bf16_t* P, long ld, i
   o.c8 = 0;
   return o;
 }
-template <int MODE>
+// NP: 1-KB pieces per wave and operand tile: 4 = a 128-row (KC) / 64-k-row (KR) tile, 2 = a 64-row KC tile (the 64 x 128 output tile)
+template <int MODE, int NP = 4>
 __device__ __forceinline__ void retarget_glds(Operand& o, long ld, int row0, int nrows, int wave, int lane, bool valid) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int piece = wave * 4 + p;
+  for (int p = 0; p < NP; ++p) {
+    const int piece = wave * NP + p;
     if (MODE == KC) {   // piece = 8 rows x 128 B; lane -> (row, physical chunk)
       int row = piece * 8 + (lane >> 3), pc = lane & 7;
       int c = pc ^ ((row >> 1) & 7);
@@ -133,18 +134,18 @@ __device__ __forceinline__ void retarget_glds(Operand& o, long ld, int row0, int
   }
 }
 // issue the 4 pieces of one operand tile for k-tile k0 into `buf` (16 KB)
-template <int MODE>
+template <int MODE, int NP = 4>
 __device__ __forceinline__ void stage_glds(const Operand& o, char* buf, int k0, int K, int wave, int lane) {
   const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)k0 * o.kstride));
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NP; ++p) {
     unsigned vo = o.voff[p];
     if (MODE == KC) {  // k tail (K % 64 != 0): this lane's logical chunk within the tile
-      int row = (wave * 4 + p) * 8 + (lane >> 3);
+      int row = (wave * NP + p) * 8 + (lane >> 3);
       int c = (lane & 7) ^ ((row >> 1) & 7);
       vo = (k0 + c * 8 < K) ? vo : FC_OOB;
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rsrc, (lds_ptr_t)(buf + (wave * 4 + p) * 1024), 16, vo, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(o.rsrc, (lds_ptr_t)(buf + (wave * NP + p) * 1024), 16, vo, soff, 0, 0);
   }
 }
 // buffer descriptor for the epilogue stores: lanes outside the matrix use an out-of-range offset, so every thread issues the

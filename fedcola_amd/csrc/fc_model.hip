@@ -80,6 +80,8 @@ struct fc_model {
   mutable hipStream_t mbs[3] = {nullptr, nullptr, nullptr};      // micro-batch chains 1..3 (chain 0 runs on the caller's stream)
   mutable hipEvent_t ev_mb_join[3] = {nullptr, nullptr, nullptr};
   ~fc_model() {
+    for (auto& kv : step_graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (adamw_dyn) (void)hipFree(adamw_dyn);
     if (tables_dev) (void)hipFree(tables_dev);
     if (shared_dev) (void)hipFree(shared_dev);
     if (reparam_dev) (void)hipFree(reparam_dev);
@@ -112,9 +114,20 @@ struct fc_model {
   // fused MLP (fc_mlp.hip): the bf16 mode of a 384-wide model reads fc1 / fc2 from streams packed in MFMA-fragment order, kept behind the
   // compute weights in the same buffer: per tower and layer a forward and a backward stream of 2 * D * Hd bf16 each
   bool mlp_fused = false;
+  bool mlp_fused_ok = false;      // the shape is covered (bf16, D = 384, Hd % 128 == 0); mlp_fused: ... and switched on (fc_model_set_option)
+  mutable bool step_graph = false;
+  // whole-step HIP graphs (fc_client_step): one executable graph per set of buffer addresses and batch shape; the three AdamW constants that
+  // change from step to step live in `adamw_dyn` (device) and are rewritten ahead of every replay
+  struct StepKey {
+    const void* p[12]; size_t ws_bytes; int B, n_txt;
+    bool operator<(const StepKey& o) const { return memcmp(this, &o, sizeof(StepKey)) < 0; }
+  };
+  struct StepEntry { int seen = 0; hipGraphExec_t exec = nullptr; bool declined = false; };
+  mutable std::map<StepKey, StepEntry> step_graphs;
+  mutable float* adamw_dyn = nullptr;
   size_t mlp_stream_elems() const { return fc_mlp_pack_elems(cfg.dim, cfg.mlp_hidden); }
   size_t mlp_pack_base() const { return ((size_t)total * fc_esize(dt) + 255) / 256 * 256; }      // byte offset of the first stream inside wc
-  size_t mlp_pack_bytes() const { return mlp_fused ? (size_t)2 * cfg.depth * 2 * mlp_stream_elems() * sizeof(bf16_t) : 0; }
+  size_t mlp_pack_bytes() const { return mlp_fused_ok ? (size_t)2 * cfg.depth * 2 * mlp_stream_elems() * sizeof(bf16_t) : 0; }
   const bf16_t* mlp_stream(const void* wc, int tower, int layer, int bwd) const {
     return (const bf16_t*)((const char*)wc + mlp_pack_base()) + ((size_t)(tower * cfg.depth + layer) * 2 + bwd) * mlp_stream_elems();
   }
@@ -161,8 +174,10 @@ extern "C" int fc_model_create(const fc_model_cfg* c, fc_model_t** out) {
   bool aux_attn = aux && !c->aux_mlp_only, aux_mlp = aux && !c->aux_attn_only;
   m->need_wc = (m->dt == FC_BF16) || aux;
   {
-    static const int on = fc_knob("FC_MLP_FUSED", 1);
-    m->mlp_fused = on && m->dt == FC_BF16 && fc_mlp_fused_ok(c->dim, c->mlp_hidden);
+    static const int on = fc_knob("FC_MLP_FUSED", 0), graph = fc_knob("FC_STEP_GRAPH", 0);      // (tools build; the product build takes fc_model_set_option)
+    m->mlp_fused_ok = m->dt == FC_BF16 && fc_mlp_fused_ok(c->dim, c->mlp_hidden);
+    m->mlp_fused = on && m->mlp_fused_ok;
+    m->step_graph = graph != 0;
   }
   int present[2] = {c->has_img, c->has_txt};
   // embeddings first (mome.py:709-723)
@@ -243,13 +258,36 @@ extern "C" int fc_model_segment(const fc_model_t* m, int32_t i, fc_segment* out)
   return 0;
 }
 extern "C" int fc_model_set_trainable(fc_model_t* m, int32_t seg, int32_t trainable) {
+  for (auto& kv : m->step_graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);      // a captured step bakes the optimizer's coverage in
+  m->step_graphs.clear();
   FC_REQUIRE(seg >= 0 && seg < (int)m->segs.size(), "fc_model_set_trainable: index %d out of range", seg);
   m->segs[seg].trainable = trainable;
   return 0;
 }
+// Run-time switches of a handle (include/fedcola_hip.h: FC_OPT_*).  All default to 0: the measured-fastest forms of the client step.
+extern "C" int fc_model_set_option(fc_model_t* m, int32_t option, int32_t value) {
+  switch (option) {
+    case FC_OPT_MLP_FUSED:
+      FC_REQUIRE(!value || m->mlp_fused_ok, "FC_OPT_MLP_FUSED: the fused MLP covers the bf16 mode of 384-wide models with mlp_hidden %% 128 == 0");
+      // switching it on needs the packed streams: they are (re)written by the next fc_prepare_weights / optimizer step; the caller must
+      // call fc_prepare_weights before the next forward
+      m->mlp_fused = value != 0;
+      for (auto& kv : m->step_graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      m->step_graphs.clear();
+      return 0;
+    case FC_OPT_STEP_GRAPH:
+      m->step_graph = value != 0;
+      return 0;
+    case FC_OPT_GEMM_FORM:
+      FC_REQUIRE(value == 0 || value == 64 || value == 3 || value == 4, "FC_OPT_GEMM_FORM: 0 (128-row tiles), 64 (64-row tiles) or 3 / 4 (64-row tiles, 3- / 4-stage ring)");
+      fc_gemm_set_form(value);
+      return 0;
+  }
+  FC_REQUIRE(false, "fc_model_set_option: unknown option %d", option);
+}
 extern "C" size_t fc_compute_weights_bytes(const fc_model_t* m) {
   if (!m->need_wc) return 0;
-  return m->mlp_fused ? m->mlp_pack_base() + m->mlp_pack_bytes() : (size_t)m->total * fc_esize(m->dt);
+  return m->mlp_fused_ok ? m->mlp_pack_base() + m->mlp_pack_bytes() : (size_t)m->total * fc_esize(m->dt);
 }
 
 // ---------------------------------------------------------------- workspace
@@ -476,7 +514,7 @@ static int reparam_table(const fc_model* m, const FcReparam** tab, int* n) {
 static int cached_table(const void* host, size_t bytes, const void** out);
 // the fused MLP's weight streams of every layer of both towers, from the bf16 compute weights in `wc` (one launch)
 static int mlp_pack_all(const fc_model* m, void* wc, hipStream_t s) {
-  if (!m->mlp_fused) return 0;
+  if (!m->mlp_fused) return 0;      // (a handle that switches the fused MLP on calls fc_prepare_weights next)
   std::vector<FcMlpPackJob> jobs;
   const bf16_t* W = (const bf16_t*)wc;
   for (int i = 0; i < 2; ++i) {
@@ -1991,12 +2029,59 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
 static hipEvent_t g_phase_ev[64 * 5];
 static bool g_phase_on = false;
 #endif
+// Whole-step graph replay.  A step of the ViT-S client is ~550 launches on four streams and costs the host 2.7-4 ms to enqueue (of a 4.4-ms
+// step): after two eager steps with the same buffers and shapes the third is captured (thread-local stream capture: the forks and joins of
+// the internal streams become graph edges) and every later one is ONE hipGraphLaunch.  Kernel arguments are baked in, so the key holds
+// every address and shape, and the step-dependent AdamW constants are read from device memory (FcAdamW::dyn).  Anything the capture cannot
+// hold (FedProx term, separate optimizer, a first step that still records which gradients need zeroing) declines and runs eagerly.
+enum { FC_STEP_DECLINED = 77 };
+static thread_local bool g_step_capture = false;
 extern "C" int fc_client_step(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
                               const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int32_t step, float* lossbuf, void* workspace, size_t workspace_bytes,
                               void* stream) {
-  return client_step_impl(m, params, grads, exp_avg, exp_avg_sq, wc, img, ids, labels, B, n_txt, droppath, lr, beta1, beta2, eps, weight_decay, step,
-                          lossbuf, workspace, workspace_bytes, stream, nullptr, 0.f, nullptr, 0);
+  auto eager = [&]() {
+    return client_step_impl(m, params, grads, exp_avg, exp_avg_sq, wc, img, ids, labels, B, n_txt, droppath, lr, beta1, beta2, eps, weight_decay, step,
+                            lossbuf, workspace, workspace_bytes, stream, nullptr, 0.f, nullptr, 0);
+  };
+  if (!m->step_graph || m->dt != FC_BF16) return eager();
+  hipStream_t s = (hipStream_t)stream;
+  fc_model::StepKey key;
+  memset(&key, 0, sizeof(key));
+  const void* ptrs[12] = {params, grads, exp_avg, exp_avg_sq, wc, img, ids, labels, droppath, lossbuf, workspace, stream};
+  memcpy(key.p, ptrs, sizeof(ptrs));
+  key.B = B; key.n_txt = n_txt; key.ws_bytes = workspace_bytes;
+  if (m->step_graphs.size() >= 16 && !m->step_graphs.count(key)) return eager();      // the addresses keep changing: stay eager
+  fc_model::StepEntry& e = m->step_graphs[key];
+  if (e.declined) return eager();
+  const FcAdamW consts = fc_adamw_consts(lr, beta1, beta2, eps, weight_decay, step);
+  if (e.exec) {
+    FC_TRY(fc_adamw_set_dyn(m->adamw_dyn, consts, s));
+    FC_CHECK_HIP(hipGraphLaunch(e.exec, s));
+    m->last = LastFwd{workspace, B, n_txt, (m->tw[0].present && m->tw[1].present) ? 1 : 0, droppath, ids};
+    return 0;
+  }
+  if (e.seen < 2) { ++e.seen; return eager(); }
+  if (!m->adamw_dyn) FC_CHECK_HIP(hipMalloc(&m->adamw_dyn, 4 * sizeof(float)));
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e.declined = true; return eager(); }
+  g_step_capture = true;
+  const int r = eager();
+  g_step_capture = false;
+  const hipError_t ce = hipStreamEndCapture(s, &graph);
+  if (r != 0 || ce != hipSuccess || !graph) {
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    e.declined = true;
+    if (r != 0 && r != FC_STEP_DECLINED) return r;
+    return eager();
+  }
+  const hipError_t ie = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ie != hipSuccess) { (void)hipGetLastError(); e.exec = nullptr; e.declined = true; return eager(); }
+  FC_TRY(fc_adamw_set_dyn(m->adamw_dyn, consts, s));
+  FC_CHECK_HIP(hipGraphLaunch(e.exec, s));
+  return 0;
 }
 extern "C" int fc_client_step_prox(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
                                    const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr,
@@ -2034,6 +2119,12 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
   // routing): the linears' and the blocks' LayerNorm gradients (93 % of the buffer) are overwritten by plain stores.  Which segments those
   // are is recorded by the first step of a handle (which zeroes everything) and depends on the model and the batch shape only.
   const bool know_cover = m->cover_B == B && m->cover_ntxt == n_txt && !m->zero_runs.empty();
+  if (g_step_capture) {      // a captured step must take the fused-optimizer path (its constants come from device memory); nothing is enqueued yet
+    bool plain = know_cover && !global_params && m->need_wc && m->dt == FC_BF16 && !m->cfg.colearn_attn && fc_knob("FC_FUSED_OPT", 1) != 0;
+    for (const fc_segment& sg : m->segs)
+      if (!sg.trainable || strstr(sg.name, "aux_weight")) plain = false;
+    if (!plain) return FC_STEP_DECLINED;
+  }
   if (know_cover) {
     for (const std::pair<int64_t, int64_t>& r : m->zero_runs) FC_CHECK_HIP(hipMemsetAsync(grads + r.first, 0, sizeof(float) * (size_t)r.second, s));
   } else {
@@ -2070,6 +2161,7 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
   const bool fused = fused_opt && fuse_shadow && !global_params && !m->cfg.colearn_attn;
   LateDw late;
   FcAdamW fo = fc_adamw_consts(lr, beta1, beta2, eps, weight_decay, step);
+  if (g_step_capture) fo.dyn = m->adamw_dyn;
   fo.g0 = grads; fo.p = params; fo.m = exp_avg; fo.v = exp_avg_sq; fo.shadow = (bf16_t*)wc;
   std::vector<char> fseg;
   late.fused = fused;

@@ -71,11 +71,12 @@ class PinnedBatchLoader:
         self.__dict__.update(d)
         self._fetch = getattr(self.dataset, "get_batch_raw" if self.raw else "get_batch", None)
 
-    def device_finish(self, tensors):
-        """After the copy to the device (on the copy's stream): raw image codes -> the dataset's float images.  Identity otherwise."""
+    def device_finish(self, tensors, out=None):
+        """After the copy to the device (on the copy's stream): raw image codes -> the dataset's float images.  Identity otherwise.
+        out: optional float32 tensor to expand into (DevicePrefetcher's fixed device ring)."""
         if self.raw and tensors and torch.is_tensor(tensors[0]) and tensors[0].dtype == torch.uint8:
             tensors = list(tensors)
-            tensors[0] = self.dataset.expand_on_device(tensors[0])
+            tensors[0] = self.dataset.expand_on_device(tensors[0], out=out)
         return tensors
 
     def __del__(self):

@@ -211,8 +211,9 @@ class DecodedCache(Dataset):
         self._fill_rest(ii, out)
         return tuple(out)
 
-    def expand_on_device(self, img):
-        """uint8 codes [b, 3, H, W] on the device -> the dataset's float32 images (fc_image_u8_to_f32 on the current stream)."""
+    def expand_on_device(self, img, out=None):
+        """uint8 codes [b, 3, H, W] on the device -> the dataset's float32 images (fc_image_u8_to_f32 on the current stream).  `out`: a float32
+        tensor of the same shape to fill (a prefetcher with a fixed device ring passes one per slot); default a new tensor."""
         if img.dtype != torch.uint8:
             return img
         from .. import _lib
@@ -221,7 +222,8 @@ class DecodedCache(Dataset):
         if lut is None:
             lut = self._lut_dev[dev] = self.lut.to(dev).contiguous()
         img = img.contiguous()
-        out = torch.empty(img.shape, dtype=torch.float32, device=dev)
+        if out is None or out.shape != img.shape or out.dtype != torch.float32 or out.device != dev:
+            out = torch.empty(img.shape, dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().fc_image_u8_to_f32(_lib.ptr(img), _lib.ptr(lut), _lib.ptr(out), img.shape[0], img.shape[1], img.shape[2] * img.shape[3],
                                                  _lib.stream_ptr()))
         return out

@@ -329,6 +329,9 @@ class ModalityAgnosticTransformer(nn.Module):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._handle = _Handle(self._handle.cfg)
+        for name, value in self.__dict__.get("_options", {}).items():    # carry over the handle's run-time switches
+            if name != "gemm_form":
+                check(_lib.lib().fc_model_set_option(new._handle.h, {"mlp_fused": _lib.FC_OPT_MLP_FUSED, "step_graph": _lib.FC_OPT_STEP_GRAPH}[name], value))
         for k, s in self.segments.items():                               # carry over freeze flags
             if not s["trainable"] and new._handle.segments[k]["trainable"]:
                 new.set_trainable(k, False)
@@ -366,6 +369,17 @@ class ModalityAgnosticTransformer(nn.Module):
         self._bump()                                                     # the compute weights are re-cast before the next forward
         self.train(src.training)
         return True
+
+    def set_option(self, name: str, value: int):
+        """Run-time switch of the library handle (include/fedcola_hip.h, FC_OPT_*): "mlp_fused" (fc1 -> GELU -> fc2 as one launch per
+        64-row panel), "step_graph" (fc_client_step replays a captured HIP graph), "gemm_form" (process-wide tile form of under-filled
+        launches: 0 | 64 | 3 | 4).  All default to 0, the forms that measure fastest in the ViT-S client step (profiles/r05)."""
+        code = {"mlp_fused": _lib.FC_OPT_MLP_FUSED, "step_graph": _lib.FC_OPT_STEP_GRAPH, "gemm_form": _lib.FC_OPT_GEMM_FORM}[name]
+        check(_lib.lib().fc_model_set_option(self._handle.h, code, int(value)))
+        opts = self.__dict__.setdefault("_options", {})
+        opts[name] = int(value)
+        if name == "mlp_fused":
+            self._wc_version = -1                  # the packed weight streams are written by the next prepare_weights()
 
     def set_trainable(self, key: str, flag: bool):
         check(_lib.lib().fc_model_set_trainable(self._handle.h, self.segments[key]["index"], int(flag)))

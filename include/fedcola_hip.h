@@ -29,7 +29,7 @@ extern "C" {
 
 #define FC_ABI_VERSION 5   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw;
                               4: fc_image_u8_to_f32, fc_k_gemm_epi; fc_k_layernorm_partial_floats counts fp64 rows;
-                              5: fc_k_mlp_pack, fc_k_mlp_fused */
+                              5: fc_k_mlp_pack, fc_k_mlp_fused, fc_model_set_option */
 
 enum { FC_PREC_FP32 = 0, FC_PREC_BF16 = 1 };
 enum { FC_TASK_NONE = 0, FC_TASK_CLS = 1, FC_TASK_RTV = 2 };
@@ -71,6 +71,16 @@ int64_t fc_model_num_params(const fc_model_t* m);        /* padded flat length i
 int32_t fc_model_num_segments(const fc_model_t* m);
 int fc_model_segment(const fc_model_t* m, int32_t i, fc_segment* out);
 int fc_model_set_trainable(fc_model_t* m, int32_t seg, int32_t trainable);  /* fedavgserver.py:422-429 freeze */
+/* Run-time switches (round 5).  Every option defaults to 0 = the forms that measure fastest in the ViT-S client step; the others are kept
+ * selectable because they are the better kernels stand-alone (profiles/r05): same results to the bit (FC_OPT_MLP_FUSED, FC_OPT_STEP_GRAPH)
+ * or to the last fp32 bits of a sum whose order does not change (FC_OPT_GEMM_FORM never changes a result: same k order per element).
+ *  FC_OPT_MLP_FUSED  1: fc1 -> GELU -> fc2 (and the backward mirror) as one launch per 64-row panel (bf16 mode, dim 384).  Call
+ *                       fc_prepare_weights after switching it on (the fused kernels read packed weight streams behind the compute weights).
+ *  FC_OPT_STEP_GRAPH 1: fc_client_step replays a captured HIP graph from the third step with the same buffers and shapes on.
+ *  FC_OPT_GEMM_FORM  process-wide: tiles of the NT / NN launches that would fill less than half of the chip: 0 = 128 x 128, 64 = 64 x 128,
+ *                       3 | 4 = 64 x 128 with a 3- / 4-stage staging ring for K >= 1024. */
+enum { FC_OPT_MLP_FUSED = 1, FC_OPT_STEP_GRAPH = 2, FC_OPT_GEMM_FORM = 3 };
+int fc_model_set_option(fc_model_t* m, int32_t option, int32_t value);
 
 /* The library's auxiliary HIP stream (hipStream_t as void*) that carries the text tower.  It idles for most of a step, so the
  * host->device copy of the NEXT batch belongs there (fedcola_amd/loaders/prefetch.py): the GPU runs at most four hardware

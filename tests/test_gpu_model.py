@@ -259,3 +259,114 @@ def test_colearn_attn_d384_bf16_shared_attention_gradients(B):
         rel = float((grads[k] - go).norm() / go.norm())
         assert rel <= 8e-2, (k, rel)
     assert "blockses.1.0.attn.qkv.weight" not in grads
+
+
+@pytest.mark.parametrize("B", [16, 32])
+def test_step_graph_replay_is_bit_identical_to_the_eager_step(B):
+    """fc_client_step replays a captured HIP graph from the third step with the same buffers on (fc_model.hip: whole-step graph).  From one
+    saved state, the captured step, a pure replay and an eager step (another loss buffer = another key = never captured) must produce the
+    same bits for everything that is not summed with atomics, with a learning rate and a step count that differ from the captured ones
+    (the AdamW constants of a replay come from device memory, not from the baked kernel arguments)."""
+    import product_util as PU
+    from synth import det_state_dict
+    from fedcola_amd import _lib
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    mk = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=384, depth=2, num_heads=6, vocab_size=64, max_text_len=16)
+    torch.manual_seed(0)
+    sd = det_state_dict({k: tuple(v.shape) for k, v in M(**mk).state_dict().items()}, base_seed=5)
+    g = torch.Generator().manual_seed(3)
+    img = (torch.randn(B, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1).cuda()
+    ids = torch.randint(1, 64, (B, 16), generator=g).cuda()
+    model = PU.build_product(mk, "bf16", sd); model.train()
+    model.set_option("step_graph", 1)
+    n = model.flat.numel()
+    st = dict(g=torch.zeros(n).cuda(), m=torch.zeros(n).cuda(), v=torch.zeros(n).cuda())
+    loss_a, loss_b = torch.zeros(2).cuda(), torch.zeros(2).cuda()
+    model.prepare_weights(force=True)
+    ws = model.workspace(B, 16)
+    P, L = _lib.ptr, _lib.lib()
+
+    def step(k, lr, lossbuf):
+        _lib.check(L.fc_client_step(model._handle.h, P(model.flat), P(st["g"]), P(st["m"]), P(st["v"]), P(model._wc_or_flat()), P(img), P(ids), None, B, 16,
+                                    None, lr, 0.9, 0.999, 1e-8, 0.01, k, P(lossbuf), P(ws), ws.numel(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+
+    def snapshot():
+        return dict(p=model.flat.detach().clone(), wc=model._wc_or_flat().detach().clone(), **{k: v.clone() for k, v in st.items()})
+
+    def restore(s):
+        model.flat.data.copy_(s["p"]); model._wc_or_flat().copy_(s["wc"])
+        for k in st: st[k].copy_(s[k])
+
+    step(1, 1e-3, loss_a); step(2, 1e-3, loss_a)          # two eager steps with these buffers ...
+    s0 = snapshot()
+    outs = {}
+    for name, k, lr, buf in (("captured", 3, 1e-3, loss_a), ("replay", 7, 3e-3, loss_a), ("eager", 7, 3e-3, loss_b), ("replay2", 7, 3e-3, loss_a)):
+        restore(s0)
+        buf.zero_()
+        step(k, lr, buf)                                    # ... the third one is captured, later ones with loss_a are replays
+        outs[name] = dict(snapshot(), loss=float(buf[1]))
+    segs = model.segments
+    for a, b in (("replay", "eager"), ("replay2", "replay")):
+        assert abs(outs[a]["loss"] - outs[b]["loss"]) <= 1e-5 * max(1.0, abs(outs[b]["loss"]))
+        n_lin = 0
+        for name, sg in segs.items():
+            o, c = int(sg["offset"]), int(sg["numel"])
+            linear = ".attn." in name or ".mlp." in name
+            for key in ("g", "p", "m", "v"):
+                x, y = outs[a][key][o:o + c], outs[b][key][o:o + c]
+                if linear:
+                    assert torch.equal(x, y), f"{a} vs {b}: {key} of {name}: {int((x != y).sum())} of {c} elements differ"
+                else:      # embedding / LayerNorm gradients are summed with atomics: equal up to the order of the sum
+                    assert float((x - y).abs().max()) <= 1e-4 * max(float(x.abs().max()), 1e-12), f"{a} vs {b}: {key} of {name}"
+            n_lin += c if linear else 0
+        assert n_lin > 0.8 * n
+    # the replayed step really used lr = 3e-3 at step 7, not the captured 1e-3 at step 3
+    assert not torch.equal(outs["captured"]["p"], outs["replay"]["p"])
+
+
+@pytest.mark.parametrize("option,value", [("mlp_fused", 1), ("gemm_form", 64), ("gemm_form", 3), ("gemm_form", 4)])
+def test_optional_kernel_forms_give_the_same_step(option, value):
+    """The forms fc_model_set_option switches on (fused MLP, 64-row GEMM tiles with or without the deep staging ring) are other schedules of
+    the same arithmetic: every product sums its k in the same order, so one client step from the same state gives the same bits in every
+    linear's gradient / parameters / moments (embedding and LayerNorm gradients are summed with atomics: equal up to the order).
+    ViT-S width, depth 2, B = 22 (three image chains of 7-8 samples beside the text tower: the under-filled launches the forms are for)."""
+    import product_util as PU
+    from synth import det_state_dict
+    from fedcola_amd import _lib
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    mk = dict(modalities=["img", "txt"], num_classes=[None, None], tasks=["rtv", "rtv"], embed_dim=384, depth=2, num_heads=6, vocab_size=64, max_text_len=16)
+    torch.manual_seed(0)
+    sd = det_state_dict({k: tuple(v.shape) for k, v in M(**mk).state_dict().items()}, base_seed=5)
+    B = 22
+    g = torch.Generator().manual_seed(3)
+    img = (torch.randn(B, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1)
+    ids = torch.randint(1, 64, (B, 16), generator=g)
+    outs = {}
+    try:
+        for tag in ("default", "option"):
+            model = PU.build_product(mk, "bf16", sd); model.train()
+            if tag == "option":
+                model.set_option(option, value)
+            n = model.flat.numel()
+            g2 = torch.Generator().manual_seed(11)
+            st = dict(grads=torch.zeros(n).cuda(), m=(torch.randn(n, generator=g2) * 1e-3).cuda(), v=(torch.rand(n, generator=g2) * 1e-5).cuda(), loss=torch.zeros(2).cuda())
+            loss, _, st = PU.product_step(model, "img+txt", img, ids, None, 1e-3, wd=0.01, step=3, state=st)
+            outs[tag] = dict(p=model.flat.detach().cpu(), m=st["m"].cpu(), v=st["v"].cpu(), g=st["grads"].cpu(), loss=loss, segs=model.segments)
+    finally:
+        if option == "gemm_form":
+            _lib.check(_lib.lib().fc_model_set_option(model._handle.h, _lib.FC_OPT_GEMM_FORM, 0))      # process-wide: back to the default
+    a, b = outs["default"], outs["option"]
+    assert abs(a["loss"] - b["loss"]) <= 1e-5 * max(1.0, abs(a["loss"]))
+    n_lin = 0
+    for name, sg in a["segs"].items():
+        o, c = int(sg["offset"]), int(sg["numel"])
+        linear = ".attn." in name or ".mlp." in name
+        for key in ("g", "p", "m", "v"):
+            x, y = a[key][o:o + c], b[key][o:o + c]
+            if linear and option == "gemm_form":
+                assert torch.equal(x, y), f"{key} of {name}: {int((x != y).sum())} of {c} elements differ"
+            else:      # atomically summed gradients; the fused MLP's residual add may contract differently (a rare one-ulp bf16 flip upstream)
+                assert float((x - y).abs().max()) <= 2e-3 * max(float(x.abs().max()), 1e-12), f"{key} of {name}"
+        n_lin += c if linear else 0
+    assert n_lin > 0.8 * a["p"].numel()
