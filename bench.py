@@ -32,7 +32,7 @@ PAIR_GFLOP = 31.61           # algorithmic GEMM FLOPs per img-txt pair fwd+bwd, 
 STEP_ALG_GB = 10.8           # algorithmic HBM bytes per B=64 step, fully fused bf16
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
 
 
 class Args:
@@ -122,7 +122,7 @@ def gemm_roofline(steps=200):
         if rec.get("source_stamp") == kernel_source_stamp() and rec.get("shape") == [ROOF_KIND, M, N, K]:
             traffic = rec.get("hbm_bytes_per_launch")
         else:
-            note = "profiles/r04/roofline_pmc.json was measured on other kernel sources / another shape: traffic withheld (re-run tools/collect_profiles.sh)"
+            note = "roofline_pmc.json was measured on other kernel sources / another shape: traffic withheld (re-run tools/collect_profiles.sh)"
     out = dict(bound="mfma", kernel=f"k_gemm_mfma<KC,KR,bf16,PLAIN> (NN dX GEMM: dh2 = gdu.W1 of the largest backward image chain) {M}x{N}x{K} bf16",
                achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
                traffic=traffic, us_per_launch=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
@@ -130,6 +130,15 @@ def gemm_roofline(steps=200):
                protocol="cold: every launch on another operand / output set out of a >= 1-GB ring (12 weight matrices)",
                traffic_counts="bytes requested by the L2s from the fabric (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc passes over the "
                               "same cold loop): Infinity-Cache hits are included, so this is an upper bound of the HBM bytes")
+    rp = os.path.join(PROFILE_DIR, "roofline_rocprof.json")      # average device-side duration of the same kernel in the same loop under rocprofv3 --kernel-trace --stats
+    out["frac_hip_events"] = out["frac"]
+    if os.path.exists(rp):
+        rec = json.load(open(rp))
+        if rec.get("shape") == [ROOF_KIND, M, N, K] and rec.get("us_per_launch"):
+            out["rocprof_us_per_launch"] = rec["us_per_launch"]
+            out["frac_rocprof"] = round(flops / (rec["us_per_launch"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4)
+            out["rocprof_source"] = rec.get("source", "profiles/r05/roofline_kernel_stats.csv") + (
+                "" if rec.get("source_stamp") == kernel_source_stamp() else " (measured on earlier kernel sources)")
     if note:
         out["traffic_note"] = note
     # the same kernel over the whole batch's rows (how the one-chain schedule launches it): a third of the batch fills 102 tiles on 256
@@ -161,6 +170,16 @@ def cpu_model_name():
     except OSError:
         pass
     return "unknown CPU"
+
+
+def cgroup_cpu_max():
+    """The CPU quota of this container ("max 100000" = none; "800000 100000" = 8 CPUs' worth), cgroup v2 then v1; None when unreadable."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            continue
+    return None
 
 
 def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
@@ -200,7 +219,7 @@ def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
     # 1.25x slower than the best so far or a third of the budget is gone (a 256-thread fp32 step can take 20 s on this host)
     best_t, best_s = None, None
     start = min(32, cores)
-    for direction in ([start, 16, 8], [64, 128, cores]):
+    for direction in ([start, 16, 8, 4, 2, 1], [64, 128, cores]):
         for t in direction:
             if t < 1 or t > cores or f"explicit@{t}" in sweep:
                 continue
@@ -224,13 +243,15 @@ def cpu_baseline_child(B, seq, vocab, warm, timed, budget_s):
         if time.perf_counter() - t_start > budget_s and len(times) >= 5:
             break
     dt = sum(times) / len(times)
-    print(json.dumps(dict(value=round(B / dt, 2), unit="img-txt pairs/s", cores=threads, kind="port", form=form, sweep_s_per_step=sweep,
+    print(json.dumps(dict(value=round(B / dt, 2), unit="img-txt pairs/s", cores=cores, threads=threads, cgroup_cpu_max=cgroup_cpu_max(), kind="port", form=form, sweep_s_per_step=sweep,
                           sample=f"{len(times)} timed + {warm} warm-up fp32 steps of the same B={B} ViT-S workload by oracle/mome_oracle.py "
                                  f"({form} backward, torch {torch.__version__} CPU ops, {threads} threads = the fastest of the sweep "
                                  f"{sweep}, {dt:.2f} s/step; host: {cpu_model_name()}, {os.cpu_count()} logical CPUs).  Both forms of the step "
                                  f"are timed (explicit backward / torch.autograd over the same forward, as the reference's loss.backward()) "
                                  f"and the faster is reported; the explicit form makes ~1.4x the elementwise passes and keeps every "
-                                 f"intermediate.  The sweep runs downward (16, 8) and upward (64, 128, all) from 32 threads")), flush=True)
+                                 f"intermediate.  The sweep runs downward (16, 8, 4, 2, 1: until a setting is 1.25x slower than the best) and "
+                                 f"upward (64, 128, all) from 32 threads; cores = CPUs this process may run on (sched_getaffinity), "
+                                 f"cgroup cpu.max = {cgroup_cpu_max()}")), flush=True)
 
 
 def cpu_baseline(B, seq, vocab, timeout=420):
@@ -309,32 +330,37 @@ def fp32_mode_line(img, ids, B, seq, dev, steps=8):
                      "attention as v_mfma_f32_16x16x4_f32 chains")
 
 
-def extra_legs(a, args, model, step, B, seq, dev, dev_step_s):
-    """h2d_inclusive: the same step with every batch coming from pinned host memory through DevicePrefetcher ("include H2D of
-    the batch (pinned, overlapped)").  client_round: FedavgClient.download() + update() (E = 1, 20 steps of B from an in-memory dataset
-    through the client's default loader) + the server's aggregation of that client, in pairs/s.  sustained: >= 6 s of back-to-back steps (long enough for a 5-s utilisation sampler to land inside it)."""
+def extra_legs(a, args, model, step, B, seq, dev, dev_step_s, make_ws=None):
+    """device_resident: the same step with the batch already in HBM (rounds 1-4's headline; the headline now takes every batch from pinned host
+    memory through DevicePrefetcher).  host_issue: what a fc_client_step call costs the host when the queue is empty.  batch_sweep:
+    t(B) at B = 64 / 96 / 128 and its linear fit (the kernels' asymptotic rate).  client_round: FedavgClient.download() + update() (E = 1, 20
+    steps of B from an in-memory dataset through the client's default loader) + the server's aggregation of that client, in pairs/s.
+    sustained: >= 6 s of back-to-back steps (long enough for a 5-s utilisation sampler to land inside it)."""
     import copy
     import torch
-    from fedcola_amd.loaders import DevicePrefetcher
     out = {}
-    # ---- h2d_inclusive
-    himg, hids = (torch.randn(B, 3, 224, 224) * 0.5).clamp_(-1, 1).pin_memory(), torch.randint(1, args.vocab_size, (B, seq)).pin_memory()
+    # ---- device_resident
     k = max(20, min(a.steps, 100))
-
-    def host_batches(nb):
-        for _ in range(nb):
-            yield himg, hids
-    it = iter(DevicePrefetcher(host_batches(k + 5), dev, depth=2, stream=model.side_stream()))
     for _ in range(5):
-        step(next(it))
+        step(resident=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(k):
-        step(next(it))
+        step(resident=True)
     torch.cuda.synchronize()
     d = time.perf_counter() - t0
-    out["h2d_inclusive"] = dict(value=round(B * k / d, 1), unit="img-txt pairs/s", ms_per_step=round(d / k * 1e3, 3), steps=k,
-                                note="every batch copied from pinned host memory (38.5 MB) by DevicePrefetcher on the library's copy stream, two batches ahead")
+    dev_step_s = d / k
+    out["device_resident"] = dict(value=round(B * k / d, 1), unit="img-txt pairs/s", ms_per_step=round(d / k * 1e3, 3), steps=k,
+                                  note="the batch sits in HBM for the whole run (no PCIe traffic in the timed region): the headline of rounds 1-4")
+    # ---- host_issue: the call alone, queue empty (enqueue_ms_per_step of the headline includes the time the host is held back by a full queue)
+    hs = []
+    for _ in range(12):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(resident=True)
+        hs.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    out["host_issue_ms_per_step"] = round(sorted(hs)[len(hs) // 2] * 1e3, 3)
     # ---- sustained
     t0 = time.perf_counter()
     ks = 0
@@ -345,6 +371,42 @@ def extra_legs(a, args, model, step, B, seq, dev, dev_step_s):
         torch.cuda.synchronize()
     d = time.perf_counter() - t0
     out["sustained"] = dict(seconds=round(d, 2), steps=ks, ms_per_step=round(d / ks * 1e3, 3), value=round(B * ks / d, 1), unit="img-txt pairs/s")
+    # ---- batch_sweep: t(B) = a + b B (a: what the dependency chain costs, b: the kernels' throughput): B = 64 / 96 / 128, device-resident
+    try:
+        from fedcola_amd import _lib
+        L, P, sp = _lib.lib(), _lib.ptr, _lib.stream_ptr()
+        n = model.flat.numel()
+        keep = model.flat.data.clone()
+        g_, m_, v_, lb_ = (torch.zeros(n, device=dev) for _ in range(3)), None, None, torch.zeros(2, device=dev)
+        g_ = list(g_)
+        pts = []
+        for Bs in (64, 96, 128):
+            bi, bd = make_batch(Bs, seq, args.vocab_size, 5, dev)
+            wsb = make_ws(Bs)
+            def one(kk):
+                _lib.check(L.fc_client_step(model._handle.h, P(model.flat), P(g_[0]), P(g_[1]), P(g_[2]), P(model._wc_or_flat()), P(bi), P(bd), None, Bs, seq, None,
+                                            1e-4, 0.9, 0.999, 1e-8, 0.0, kk, P(lb_), P(wsb), wsb.numel(), sp))
+            for kk in range(1, 6):
+                one(kk)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for kk in range(6, 26):
+                one(kk)
+            torch.cuda.synchronize()
+            pts.append((Bs, (time.perf_counter() - t0) / 20 * 1e3))
+        model.flat.data.copy_(keep)
+        model.prepare_weights(force=True)
+        make_ws(B)
+        xs, ys = [p[0] for p in pts], [p[1] for p in pts]
+        mx, my = sum(xs) / 3, sum(ys) / 3
+        slope = sum((x - mx) * (y - my) for x, y in pts) / sum((x - mx) ** 2 for x in xs)
+        icpt = my - slope * mx
+        out["batch_sweep"] = dict(ms_per_step={str(b): round(t, 3) for b, t in pts}, fit_ms=f"{icpt:.3f} + {slope:.5f} * B",
+                                  asymptote_tflops=round(PAIR_GFLOP / slope, 1), asymptote_mfma_frac=round(PAIR_GFLOP / slope / PEAK_BF16_TFLOPS, 4),
+                                  note="device-resident steps at B = 64 / 96 / 128, least-squares line: the intercept is the dependency chain's latency, the slope "
+                                       "the kernels' throughput per pair (its reciprocal x 31.61 GFLOP = the rate the step approaches at large B)")
+    except Exception as e:      # the sweep must never cost the line
+        out["batch_sweep"] = dict(error=f"{type(e).__name__}: {e}"[:200])
     # ---- client_round
     from fedcola_amd import aggregate as agg
     from fedcola_amd.client.fedavgclient import FedavgClient
@@ -411,6 +473,38 @@ def launch_ranks(a, argv):
     return child.wait()
 
 
+def client_plan(world, cpr):
+    """Which sampled client trains where: position p of the sorted sampled list runs on rank p % world (fedavgserver.py:310-311:
+    device = cuda:(i % n_gpu) by position), as that rank's (p // world)-th client.  One process per GPU: rank r drives cuda:r."""
+    return [dict(client=p, rank=p % world, device=f"cuda:{p % world}", queue_position=p // world) for p in range(world * cpr)]
+
+
+def dry_run(a):
+    """`--dry-run`: the rank -> client -> device plan, the all-reduce message and the launch command of an N-GPU run, WITHOUT touching a GPU
+    (the model is only constructed on the host to count its parameters).  tests/test_bench_dry_run.py asserts on it, so that the driver's
+    8-GPU run cannot fail on bookkeeping."""
+    from fedcola_amd.mome import create_model
+    args = Args()
+    args.precision = a.precision
+    model = create_model("mome_small_patch16", False, args=args, num_classes=[None, None], modalities=["img", "txt"], tasks=["rtv", "rtv"])
+    n = model.flat.numel()
+    world, cpr = a.gpus, max(1, a.clients_per_rank) if a.gpus > 1 else 1
+    plan = client_plan(world, cpr)
+    keys = list(model.required_params().keys())
+    msg = 4 * n
+    out = dict(dry_run=True, n_gpus=world, clients_per_rank=cpr, sampled_clients=len(plan), plan=plan,
+               pairs_per_step_all_ranks=world * a.batch, params=n, aggregated_keys=len(keys),
+               allreduce=dict(collectives_per_round=(1 if world > 1 else 0), message_bytes=(msg if world > 1 else 0), message_MB=round(msg / 1e6, 1),
+                              dtype="f32", op="sum", pre_scaled_by="closed-form weights of the sequential blend (fedcola_amd/aggregate.py)",
+                              ring_one_link_ms=(round(2 * (world - 1) / world * msg / 153e9 * 1e3, 2) if world > 1 else 0.0),
+                              direct_all_links_ms=(round(2 * (world - 1) / world * msg / (153e9 * max(world - 1, 1)) * 1e3, 2) if world > 1 else 0.0)),
+               launch=(["python", "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", "<free port>",
+                        "bench.py", "--gpus", str(world), "--steps", str(a.steps), "--warmup", str(a.warmup)] if world > 1 else ["python", "bench.py"]),
+               batch_feed=("device-resident" if a.device_resident else "pinned host memory -> DevicePrefetcher (H2D inclusive)"))
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -428,17 +522,24 @@ def main():
                     "samples more than it has devices, fedavgserver.py:310-311): each rank trains its clients one after the other and "
                     "pre-accumulates them locally in ONE blend before the all-reduce")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the h2d_inclusive / client_round / sustained legs (N = 1)")
-    ap.add_argument("--h2d", action="store_true", help="non-default: batches start in pinned host memory and reach the GPU through "
-                    "fedcola_amd.loaders.DevicePrefetcher (PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--device-resident", action="store_true", help="non-default: the batch sits in HBM for the whole run.  The default (SURVEY 8d: "
+                    "\"include H2D of the batch (pinned, overlapped)\") takes every batch from pinned host memory through "
+                    "fedcola_amd.loaders.DevicePrefetcher; the device-resident rate is reported beside it as the `device_resident` leg")
+    ap.add_argument("--h2d", action="store_true", help=argparse.SUPPRESS)      # (the default since round 5)
     ap.add_argument("--fedprox-mu", type=float, default=0.0, help="non-default workload: FedproxClient step (proximal term, row N3)")
     ap.add_argument("--dropout", type=float, default=0.0, help="drop-path rate of the headline line (reference default 0.1 is the second line)")
     ap.add_argument("--dump-agg", default=None, help="directory: every rank saves its client's weights before the aggregation and rank 0 the "
                     "global model before / after it (tests/test_gpu_bench.py)")
+    ap.add_argument("--dry-run", action="store_true", help="print the rank -> client -> device plan, the all-reduce message size and the launch command "
+                    "of this configuration as one JSON line and exit, without touching a GPU")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    a.h2d = not a.device_resident
     if a.cpu_baseline_child:
         cpu_baseline_child(a.batch, Args.seq_len, Args.vocab_size, warm=3, timed=10, budget_s=240)
         return 0
+    if a.dry_run:
+        return dry_run(a)
     in_job = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if a.gpus > 1 and not in_job:
         return launch_ranks(a, sys.argv[1:])
@@ -497,14 +598,18 @@ def main():
         def host_batches():
             while True:
                 yield himg, hids
-        feed = iter(DevicePrefetcher(host_batches(), dev, depth=2, stream=model.side_stream()))
+        feed = iter(DevicePrefetcher(host_batches(), dev, depth=2, stream=model.side_stream(), reuse_device=True))
 
     dp_gen = torch.Generator(device=dev)
     dp_gen.manual_seed(77 + rank)
 
-    def step(batch=None, drop_model=None):
+    img0, ids0 = img, ids
+
+    def step(batch=None, drop_model=None, resident=False):
         nonlocal img, ids
-        if feed is not None:
+        if resident:
+            img, ids = img0, ids0
+        elif feed is not None and batch is None:
             img, ids = next(feed)
         if batch is not None:
             img, ids = batch[0], batch[1]
@@ -551,7 +656,7 @@ def main():
 
     agg_state = {}
     cpr = max(1, a.clients_per_rank) if world > 1 else 1
-    local_cids = [rank + world * j for j in range(cpr)] if world > 1 else [0]
+    local_cids = [c["client"] for c in client_plan(world, cpr) if c["rank"] == rank] if world > 1 else [0]
     # more clients than ranks: every local client has its own weights; the one model object (handle, workspace, optimizer buffers) trains
     # them one after the other, as FedavgServer's per-device queue does
     client_flats = {c: model.flat.data.clone() for c in local_cids} if cpr > 1 else None
@@ -681,7 +786,7 @@ def main():
 
     # second throughput line: the reference's default --dropout 0.1 (timm DropPath, mome.py:213,223,726-728), fewer steps, same protocol
     drop_line = None
-    if rank == 0 and world == 1 and not a.no_dropout_line and a.dropout == 0.0 and not a.h2d and a.fedprox_mu == 0:
+    if rank == 0 and world == 1 and not a.no_dropout_line and a.dropout == 0.0 and a.fedprox_mu == 0:
         a2 = Args()
         a2.precision, a2.dropout = a.precision, 0.1
         dm = create_model("mome_small_patch16", False, args=a2, num_classes=[None, None], modalities=["img", "txt"], tasks=["rtv", "rtv"])
@@ -701,12 +806,12 @@ def main():
 
     # ---- N = 1: what the metric names ("per client round"), and a leg long enough for the driver's gpu_busy sampling
     extra = {}
-    if rank == 0 and world == 1 and not a.no_extra_legs and not a.h2d and a.fedprox_mu == 0:
-        extra = extra_legs(a, args, model, step, B, seq, dev, dt / a.steps)
+    if rank == 0 and world == 1 and not a.no_extra_legs and a.fedprox_mu == 0:
+        extra = extra_legs(a, args, model, step, B, seq, dev, dt / a.steps, make_ws=lambda b: model.workspace(b, seq))
 
     fp32_line = None
-    if rank == 0 and world == 1 and not a.no_extra_legs and a.precision == "bf16" and not a.h2d and a.fedprox_mu == 0 and a.dropout == 0.0:
-        fp32_line = fp32_mode_line(img, ids, B, seq, dev)
+    if rank == 0 and world == 1 and not a.no_extra_legs and a.precision == "bf16" and a.fedprox_mu == 0 and a.dropout == 0.0:
+        fp32_line = fp32_mode_line(img0, ids0, B, seq, dev)
 
     if rank == 0:
         pairs = world * cpr * B * a.steps / dt
@@ -716,7 +821,7 @@ def main():
                    config=dict(workload="Flickr30k FedCola, 1 img-txt client per GPU, mome_small_patch16 (ViT-S + 12x384 text tower), "
                                         f"B={B}, 224x224 RGB, {seq}-token captions, vocab 7732, AdamW lr 1e-4, drop-path {a.dropout:g}"
                                         + (f", FedProx mu={a.fedprox_mu}" if a.fedprox_mu > 0 else "")
-                                        + (", batches from host memory through the device prefetcher" if a.h2d else ""),
+                                        + (", every batch from pinned host memory through the device prefetcher (H2D inclusive)" if a.h2d else ", batch resident in HBM"),
                                global_batch=world * B, parallelism=f"{world} concurrent clients + RCCL FedAvg all-reduce"
                                + (f"; {cpr} sampled clients queued per GPU, pre-accumulated locally before the all-reduce" if cpr > 1 else "")),
                    step_mfma_frac=round(pairs * PAIR_GFLOP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),

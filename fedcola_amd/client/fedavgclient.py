@@ -58,7 +58,10 @@ class FedavgClient(BaseClient):
         # (worker threads would reorder their RNG draws).  args.fast_loader = True / False and args.decode_cache = False override.
         from ..loaders.cache import DecodedCache
         cuda = torch.cuda.is_available()
-        cacheable = getattr(self.args, "decode_cache", cuda) and not hasattr(dataset, "get_batch") and DecodedCache.applicable(dataset)
+        # (nothing is fetched -- no RNG draw -- unless the fast loader and the cache are both wanted: args.fast_loader = False or
+        # args.decode_cache = False must leave the reference's sample and shuffle stream untouched)
+        want_fast = getattr(self.args, "fast_loader", None)
+        cacheable = want_fast is not False and getattr(self.args, "decode_cache", cuda) and not hasattr(dataset, "get_batch") and DecodedCache.applicable(dataset)
         if getattr(self.args, "fast_loader", cuda and (hasattr(dataset, "get_batch") or cacheable)):
             from ..loaders.batch import PinnedBatchLoader
             if cacheable:

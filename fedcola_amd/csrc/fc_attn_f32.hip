@@ -188,7 +188,8 @@ __device__ __forceinline__ void attn_f32_dq_body(float* smf, int bh, const float
       const f32x4 dpt = dot_hd(vf, dof, ndof);                            // dP^T[key][q]
       f32x4 ds;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) ds[v] = expf(st[v] * scale - lq) * (dpt[v] - dl);   // padded keys: their K rows are zero below
+      for (int v = 0; v < 4; ++v)      // padded keys are masked explicitly, as in the forward: with lse below about -88 their exp overflows and inf x 0 (their zero K rows) is NaN
+        ds[v] = (16 * f + 4 * g + v < N) ? expf(st[v] * scale - lq) * (dpt[v] - dl) : 0.f;
       if (f & 1) acc_rows(dqn, Ks, f * 16, -ds, c, g);                      // dQ[q = c][d] over the keys; odd blocks negated
       else acc_rows(dq, Ks, f * 16, ds, c, g);
     }

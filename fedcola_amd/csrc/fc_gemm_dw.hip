@@ -325,7 +325,9 @@ __device__ __forceinline__ void dws_kstep(unsigned lb, unsigned po, const DwKeys
 }
 
 #define DWS_SLOT 32768   // one stage: 4 images of [32 k][128 cols]
-template <bool OPT>
+// NSLOT: stages of the ring (4: 128 KB of LDS, three stages in flight; 3: 96 KB, two in flight -- leaves room for a 64-KB GEMM workgroup of a
+// backward chain on the same CU)
+template <bool OPT, int NSLOT>
 __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o_) {
   const FcAdamW o = fc_adamw_resolve(o_);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -369,7 +371,7 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
       const int img = 2 * lw + im;                                                                                           \
       unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((st) * 32) * (img == 0 ? oa.kstride : ob.kstride))) + \
                     (img == 0 ? 0u : 256u * (unsigned)(img - 1));                                                            \
-      char* dst = smem + ((st) & 3) * DWS_SLOT + img * 8192;                                                                  \
+      char* dst = smem + ((st) % NSLOT) * DWS_SLOT + img * 8192;                                                              \
       _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                                         \
         const int h = (p >> 1) & 1;                                                                                          \
         if (img == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(oa.rsrc, (lds_ptr_t)(dst + p * 1024), 16, vA[h], so, 0, 0);     \
@@ -379,12 +381,13 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
     }                                                                                                                        \
   } while (0)
     // rows past K read as zeros (descriptor bounds), so stages past S may be issued freely: the counted wait stays uniform
-    DWS_ISSUE(0); DWS_ISSUE(1); DWS_ISSUE(2);
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");          // 16 per stage and wave: stage 0 has landed
+    DWS_ISSUE(0); DWS_ISSUE(1);
+    if (NSLOT == 4) DWS_ISSUE(2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * (NSLOT - 2)) : "memory");   // 16 per stage and wave: stage 0 has landed
     __builtin_amdgcn_s_barrier();
     for (int st = 0; st < S; ++st) {
-      DWS_ISSUE(st + 3);                                       // slot (st + 3) & 3 = (st - 1) & 3: its readers passed the barrier above
-      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");        // stage st + 1 has landed (st + 2, st + 3 may still fly)
+      DWS_ISSUE(st + NSLOT - 1);                               // the slot of stage st - 1: its readers passed the barrier above
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * (NSLOT - 2)) : "memory");   // stage st + 1 has landed (the younger ones may still fly)
       __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the over-issued stages land before the epilogue reuses the LDS
@@ -408,7 +411,7 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
     const bool colsum = do_colsum && wn == 0;
     __builtin_amdgcn_s_barrier();                              // stage 0 has landed
     for (int st = 0; st < S; ++st) {
-      dws_kstep<0>(lb, (unsigned)((st & 3) * DWS_SLOT), kx, acc, cs4, colsum);
+      dws_kstep<0>(lb, (unsigned)((st % NSLOT) * DWS_SLOT), kx, acc, cs4, colsum);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of this slot is done before it is refilled
       __builtin_amdgcn_s_barrier();
     }
@@ -434,24 +437,30 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
     }
   }
   lds_barrier();
-  // ---- output (consumer threads 0..511; the loader waves only keep the barrier count)
+  // ---- output (consumer threads 0..511; the loader waves only keep the barrier count).  NSLOT == 4: the two 64-row halves of the tile go
+  // through a [64][388] fp32 image (99 KB); NSLOT == 3 (96 KB of LDS): four passes of 32 rows through a [32][388] image
   float* Cs = (float*)smem;
   const int g = lane >> 4, cl = lane & 15;
+  constexpr int PR = NSLOT == 4 ? 64 : 32, NPASS = 128 / PR, IB = PR / 16;      // rows per pass, passes, 16-row blocks of a wave per pass
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if (!loader && wm == h) {
+  for (int h = 0; h < NPASS; ++h) {
+    if (!loader && wm == (h * PR) / 64) {
+      const int i0 = ((h * PR) % 64) / 16;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < IB; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          *(float4*)(Cs + (i * 16 + cl) * DW_LD + wn * 96 + j * 16 + 4 * g) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        for (int j = 0; j < 6; ++j) {
+          const f32x4 v = acc[NSLOT == 4 ? i : (h & 1) * 2 + i][j];
+          (void)i0;
+          *(float4*)(Cs + (i * 16 + cl) * DW_LD + wn * 96 + j * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
     lds_barrier();
     if (!loader) {
 #pragma unroll 4
-      for (int q = 0; q < 12; ++q) {
+      for (int q = 0; q < PR * 96 / 512; ++q) {
         const int f = tid + 512 * q, row = f / 96, c4 = (f % 96) * 4;
-        const int m = m0 + 64 * h + row, n = n0 + c4;
+        const int m = m0 + PR * h + row, n = n0 + c4;
         if (m < M && n < N) {
           float* dst = P.C + (size_t)m * P.ldc + n;
           float4 gv = *(const float4*)(Cs + row * DW_LD + c4);
@@ -499,14 +508,29 @@ int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hi
   static const int form_env = fc_knob("FC_DW_WIDE", 2);      // 1: 8 waves, 2: 8 consumer + 2 loader waves
   const int form = form_arg ? form_arg : form_env;
   if (form == 2) {
+    static const int slots = fc_knob("FC_DW_SLOTS", 4);
     static bool done2 = false;
     if (!done2) {
-      FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * DWS_SLOT));
+      FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * DWS_SLOT));
       done2 = true;
     }
-    if (opt) hipLaunchKernelGGL(k_gemm_dw_spec<true>, dim3(total_tiles), dim3(640), lds, s, probs_dev, nprob, *opt);
-    else hipLaunchKernelGGL(k_gemm_dw_spec<false>, dim3(total_tiles), dim3(640), lds, s, probs_dev, nprob, FcAdamW());
+    if (slots == 3) {
+      const int lds3 = 3 * DWS_SLOT;      // 96 KB: the epilogue goes through a [32][388] image in four passes
+      static bool done3 = false;
+      if (!done3) {
+        FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+        FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+        done3 = true;
+      }
+      if (opt) hipLaunchKernelGGL((k_gemm_dw_spec<true, 3>), dim3(total_tiles), dim3(640), lds3, s, probs_dev, nprob, *opt);
+      else hipLaunchKernelGGL((k_gemm_dw_spec<false, 3>), dim3(total_tiles), dim3(640), lds3, s, probs_dev, nprob, FcAdamW());
+    } else {
+      if (opt) hipLaunchKernelGGL((k_gemm_dw_spec<true, 4>), dim3(total_tiles), dim3(640), lds, s, probs_dev, nprob, *opt);
+      else hipLaunchKernelGGL((k_gemm_dw_spec<false, 4>), dim3(total_tiles), dim3(640), lds, s, probs_dev, nprob, FcAdamW());
+    }
     FC_LAUNCH_CHECK();
     return 0;
   }

@@ -335,10 +335,12 @@ __global__ void __launch_bounds__(256) k_dw_x3_reduce(const float* __restrict__ 
 
 // per-stream scratch for the slices' partial tiles (a stream runs one weight-gradient product at a time)
 static std::mutex g_x3_mu;
-static std::map<hipStream_t, std::pair<char*, size_t>> g_x3_ws;
+static std::map<std::pair<int, hipStream_t>, std::pair<char*, size_t>> g_x3_ws;      // keyed by (device, stream): the null stream / equal handles on two devices must not share an allocation
 static int x3_scratch(hipStream_t s, size_t bytes, char** out) {
   std::lock_guard<std::mutex> lk(g_x3_mu);
-  auto& w = g_x3_ws[s];
+  int dev = 0;
+  FC_CHECK_HIP(hipGetDevice(&dev));
+  auto& w = g_x3_ws[std::make_pair(dev, s)];
   if (w.second < bytes) {
     if (w.first) {
       FC_CHECK_HIP(hipStreamSynchronize(s));

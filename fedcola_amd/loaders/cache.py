@@ -20,8 +20,8 @@ pinned batch.  What it stores:
 
 The build decodes each image once, through the dataset's own ``__getitem__`` (same PIL / transform / tokenizer code), on a few
 threads, the first time the cache is used (``build()``; clients persist across rounds, so once per client).  A dataset whose
-transform is RANDOM is detected (the first sample is fetched twice) and refused: ``applicable()`` is False and the client keeps the
-reference's DataLoader.  Index order is the loader's business (``PinnedBatchLoader`` = the DataLoader's order under the same RNG
+transform is RANDOM is refused -- decided from the transform chain's class names, with a repeated-fetch probe (RNG state saved and
+restored) only for members that cannot be judged by name: ``applicable()`` is False and the client keeps the reference's DataLoader.  Index order is the loader's business (``PinnedBatchLoader`` = the DataLoader's order under the same RNG
 state); the values are the dataset's own, bit for bit (tests/test_data_golden.py)."""
 from __future__ import annotations
 
@@ -84,18 +84,59 @@ class DecodedCache(Dataset):
                 setattr(self, attr, getattr(dataset, attr))
 
     # ------------------------------------------------------------------ applicability
-    @staticmethod
-    def applicable(dataset) -> bool:
-        """A caption dataset (image_key) whose samples are a pure function of the index: the first sample fetched twice is the same
-        tensor (a random crop / flip / jitter transform fails this and keeps the reference's loader)."""
+    # transforms by class name (torchvision's; the stub classes of the tests carry the same names): a chain made of the first set only is a
+    # pure function of the image, one member of the second set makes the sample random
+    _DETERMINISTIC = {"ToTensor", "Normalize", "Resize", "CenterCrop", "ToPILImage", "PILToTensor", "ConvertImageDtype", "Grayscale", "Pad",
+                      "FiveCrop", "TenCrop", "Compose"}
+    _RANDOM_PREFIXES = ("Random", "Rand", "Auto", "Trivial", "AugMix", "ColorJitter", "GaussianBlur", "ElasticTransform")
+
+    @classmethod
+    def _transform_verdict(cls, t):
+        """"det" | "random" | "unknown" for a transform (chains through .transforms)."""
+        if t is None:
+            return "det"
+        name = type(t).__name__
+        if name.startswith(cls._RANDOM_PREFIXES):
+            return "random"
+        inner = getattr(t, "transforms", None)
+        if inner is not None and not callable(inner):
+            verdicts = [cls._transform_verdict(u) for u in inner]
+            return "random" if "random" in verdicts else ("unknown" if "unknown" in verdicts else "det")
+        return "det" if name in cls._DETERMINISTIC else "unknown"      # Lambda, user callables: cannot be judged by name
+
+    @classmethod
+    def applicable(cls, dataset, probe_samples: int = 3, probe_repeats: int = 4) -> bool:
+        """A caption dataset (image_key) whose samples are a pure function of the index.  Decided from the transform chain: any Random* /
+        ColorJitter / Auto-augment member refuses (the client keeps the reference's loader); a chain of known deterministic transforms
+        (the reference's --resize / --imnorm: Resize, ToTensor, Normalize) accepts without fetching anything.  Only chains with members that
+        cannot be judged by name (torchvision's Lambda -- the reference pads its chains with identity Lambdas -- or user callables) are
+        probed: `probe_samples` samples fetched `probe_repeats` times each must come back identical (one pair of fetches, as in round 4,
+        passes a RandomHorizontalFlip(0.5) every second time and then freezes ONE augmented view per image), with the torch / numpy / python
+        RNG states saved before and restored after, so that a probe never shifts the shuffle or augmentation stream of the run."""
         base, _ = _resolve(dataset)
         if base is None or len(dataset) == 0:
             return False
+        verdict = cls._transform_verdict(getattr(base, "transform", None))
+        if verdict == "random":
+            return False
+        import random as _random
+        st_t, st_n, st_p = torch.get_rng_state(), np.random.get_state(), _random.getstate()
         try:
-            a, b = dataset[0], dataset[0]
+            n = len(dataset)
+            picks = sorted({0, n // 2, n - 1})[:max(1, probe_samples)] if verdict == "unknown" else [0]
+            reps = probe_repeats if verdict == "unknown" else 1
+            for i in picks:
+                a = dataset[i]
+                if not (torch.is_tensor(a[0]) and a[0].dtype == torch.float32 and a[0].dim() == 3 and torch.is_tensor(a[1])):
+                    return False
+                for _ in range(reps - 1):
+                    if not torch.equal(a[0], dataset[i][0]):
+                        return False
+            return True
         except Exception:                              # unreadable data: let the ordinary loader raise where the reference would
             return False
-        return torch.is_tensor(a[0]) and a[0].dtype == torch.float32 and a[0].dim() == 3 and torch.equal(a[0], b[0]) and torch.is_tensor(a[1])
+        finally:
+            torch.set_rng_state(st_t); np.random.set_state(st_n); _random.setstate(st_p)
 
     def __len__(self):
         return len(self.dataset)
@@ -109,6 +150,15 @@ class DecodedCache(Dataset):
     def __setstate__(self, d):
         self.__dict__.update(d)
         self._lock = threading.Lock()
+
+    def __deepcopy__(self, memo):
+        """A copied client shares the decoded store (read-only after build()) instead of duplicating hundreds of MB per copy."""
+        new = DecodedCache.__new__(DecodedCache)
+        new.__dict__.update(self.__dict__)
+        new._lock = threading.Lock()
+        new._lut_dev = {}
+        memo[id(self)] = new
+        return new
 
     def _base_index(self, i):
         return int(i) if self.index is None else int(self.index[i])
@@ -135,13 +185,36 @@ class DecodedCache(Dataset):
         C, H, W = s0[0].shape
         self.tokens = torch.empty((n,) + tuple(s0[1].shape), dtype=s0[1].dtype)
         self.meta = [None] * n
-        imgs = torch.empty((len(uniq), C, H, W), dtype=torch.float32)
         rep = set(first.values())                      # the sample that decodes each image
+        # Host memory: an image is turned into uint8 codes (and verified bit for bit) as soon as it is decoded, inside the worker, so the build
+        # holds ONE byte per pixel-channel plus a float image per worker thread -- not the whole client in fp32 with int64 temporaries beside it
+        # (> 7 GB for a 6 000-image 224 x 224 client).  The table is chosen on the first image; an image that does not invert under
+        # it keeps its floats, and if any did the store falls back to float32 (the verified images are regenerated from their codes: same bits).
+        lut = None
+        if self.store_kind in ("auto", "uint8") and C == 3:
+            x0 = s0[0].numpy()
+            for norm in self.norms:
+                cand = _lut(norm)
+                if self._codes(x0, cand.numpy()) is not None:
+                    lut = cand
+                    break
+        lut_np = lut.numpy() if lut is not None else None
+        u8 = np.empty((len(uniq), C, H, W), dtype=np.uint8) if lut is not None else None
+        floats = {} if lut is not None else None       # row -> float image that did not invert
+        imgs = torch.empty((len(uniq), C, H, W), dtype=torch.float32) if lut is None else None
 
         def job(i):
             if i in rep:
                 item = self.dataset[i]
-                imgs[self.row[i]].copy_(item[0])
+                r = int(self.row[i])
+                if lut is None:
+                    imgs[r].copy_(item[0])
+                else:
+                    code = self._codes(item[0].numpy(), lut_np)
+                    if code is None:
+                        floats[r] = item[0].clone()
+                    else:
+                        u8[r] = code
             else:                                      # tokens / ids only: no image decode (the dataset may offer it; else the full fetch)
                 item = self.base.sample_without_image(self._base_index(i)) if hasattr(self.base, "sample_without_image") else self.dataset[i]
             self.tokens[i].copy_(torch.as_tensor(item[1]))
@@ -150,15 +223,19 @@ class DecodedCache(Dataset):
         with ThreadPoolExecutor(self.workers) as pool:
             list(pool.map(job, range(n)))
         self.lut, self.u8 = None, None
-        if self.store_kind in ("auto", "uint8") and C == 3:
-            for norm in self.norms:
-                lut = _lut(norm)
-                if self._try_uint8(imgs, lut):
-                    self.lut = lut
-                    break
-        if self.lut is None:
+        if lut is not None and not floats:
+            self.lut, self.u8 = lut, torch.from_numpy(u8)
+            self._u8_np, self._lut_np = u8, lut_np
+        else:
             if self.store_kind == "uint8":
                 raise ValueError("DecodedCache(store='uint8'): the decoded images are not uint8 values under a ToTensor / Normalize table")
+            if imgs is None:                           # some images did not invert: floats for all (the inverted ones regenerate exactly)
+                imgs = torch.empty((len(uniq), C, H, W), dtype=torch.float32)
+                for r in range(len(uniq)):
+                    if r in floats:
+                        imgs[r].copy_(floats[r])
+                    else:
+                        imgs[r].copy_(torch.from_numpy(np.stack([np.take(lut_np[c], u8[r, c]) for c in range(3)])))
             self.f32 = imgs
         self.meta_cols = None
         if n and all(isinstance(v, (int, np.integer)) for m in self.meta for v in m):
@@ -168,22 +245,19 @@ class DecodedCache(Dataset):
                     (self.u8.numel() if self.lut is not None else self.f32.numel() * 4) / 1e6)
         return self
 
-    def _try_uint8(self, imgs, lut) -> bool:
-        """Invert the per-channel table on every image and regenerate: bit-identical or nothing."""
-        lut_np = lut.numpy()
-        u8 = np.empty(tuple(imgs.shape), dtype=np.uint8)
-        x = imgs.numpy()
+    @staticmethod
+    def _codes(x, lut_np):
+        """uint8 codes [3, H, W] of ONE float image under the per-channel table, or None unless the table regenerates it bit for bit."""
+        out = np.empty(x.shape, dtype=np.uint8)
         for c in range(3):
             t = lut_np[c]
             if not np.all(np.diff(t) > 0):
-                return False
-            code = np.searchsorted(t, x[:, c], side="left").clip(0, 255)
-            if not np.array_equal(t[code], x[:, c]):
-                return False
-            u8[:, c] = code.astype(np.uint8)
-        self.u8 = torch.from_numpy(u8)
-        self._u8_np, self._lut_np = u8, lut_np
-        return True
+                return None
+            code = np.searchsorted(t, x[c], side="left").clip(0, 255)
+            if not np.array_equal(t[code], x[c]):
+                return None
+            out[c] = code.astype(np.uint8)
+        return out
 
     # ------------------------------------------------------------------ fetch
     def _image(self, r):

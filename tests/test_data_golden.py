@@ -330,3 +330,68 @@ def test_decoded_cache_refuses_random_transforms_and_keeps_floats_when_uint8_wou
     with pytest.raises(ValueError):
         DecodedCache(odd, store="uint8").build()
     assert not DecodedCache.applicable(torch.utils.data.TensorDataset(torch.zeros(4, 3, 8, 8)))     # no image_key: not a caption dataset
+
+
+def test_decoded_cache_applicability_is_decided_from_the_transform_chain(tmp_path):
+    """one pair of equal fetches does not prove a transform deterministic -- RandomHorizontalFlip(0.5) passes it every second
+    time and the cache would then freeze ONE augmented view per image.  Random* / ColorJitter members refuse by class name without a fetch;
+    chains of known deterministic transforms accept without a fetch; unknown callables are probed several times on several samples, and no
+    probe may move the torch / numpy / python RNG streams (the run's shuffle and augmentation order must stay the reference's)."""
+    import random
+    from fedcola_amd.datasets.flickr30k import Flickr30kCap
+    from fedcola_amd.loaders import DecodedCache
+    root = str(tmp_path)
+    _make_flickr(root, n_images=4)
+    base = _imnorm(8)
+
+    class RandomHorizontalFlip:                      # torchvision's class name and behaviour (p = 0.5, one torch.rand(1) draw per call)
+        def __call__(self, x):
+            return x.flip(-1) if torch.rand(1) < 0.5 else x
+
+    class ToTensor:                                  # a known deterministic name
+        def __call__(self, im):
+            return base(im)
+
+    class Compose:
+        def __init__(self, ts):
+            self.transforms = ts
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    calls = []
+
+    class Counting(Flickr30kCap):
+        def __getitem__(self, i):
+            calls.append(i)
+            return super().__getitem__(i)
+
+    def states():
+        return torch.get_rng_state().clone(), np.random.get_state()[1].copy(), random.getstate()
+
+    def same(a, b):
+        return torch.equal(a[0], b[0]) and bool((a[1] == b[1]).all()) and a[2] == b[2]
+
+    # (1) a named random member: refused without fetching a sample or drawing a number
+    ds = Counting(root, split="train", transform=Compose([ToTensor(), RandomHorizontalFlip()]), tokenizer=_tok, max_length=8)
+    s0 = states()
+    assert not DecodedCache.applicable(ds) and calls == [] and same(s0, states())
+    # (2) the same flip hidden in a lambda (unknown by name): the repeated probe catches it, and the RNG streams come back untouched
+    flip = RandomHorizontalFlip()
+    hidden = Counting(root, split="train", transform=lambda im: flip(base(im)), tokenizer=_tok, max_length=8)
+    verdicts = []
+    for seed in range(20):
+        torch.manual_seed(seed)
+        s0 = states()
+        verdicts.append(DecodedCache.applicable(hidden))
+        assert same(s0, states())
+    assert sum(verdicts) <= 1                        # 3 samples x 4 fetches: all agree with probability 2^-9 per call
+    # (3) known deterministic names only: accepted on the structure plus ONE sample's type check, no repeated fetches
+    calls.clear()
+    det = Counting(root, split="train", transform=Compose([ToTensor()]), tokenizer=_tok, max_length=8)
+    assert DecodedCache.applicable(det) and len(calls) == 1
+    # (4) an unknown but deterministic callable (the reference pads its chains with identity Lambdas): accepted after the probe
+    calls.clear()
+    lam = Counting(root, split="train", transform=lambda im: base(im), tokenizer=_tok, max_length=8)
+    assert DecodedCache.applicable(lam) and len(calls) == 3 * 4

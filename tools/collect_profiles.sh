@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun) from the repo root: collects everything profiles/rNN/ holds.  usage: tools/collect_profiles.sh r02
-R=${1:-r04}
+R=${1:-r05}
 OUT=gpurun_out/$R
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -14,6 +14,12 @@ done
 mkdir -p profiles/$R
 python tools/roofline_pmc.py profiles/$R /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES_GRBM_GUI_ACTIVE /tmp/pmc_SQ_LDS_BANK_CONFLICT > "$OUT/roofline_pmc_print.txt" 2>&1
 cp profiles/$R/roofline_pmc.json "$OUT/roofline_pmc.json"
+# 2b. the roofline kernel alone: device-side duration to compare with roofline.us_per_launch (HIP events inside bench.py)
+GEMM_SHAPES="$ROOF" timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gtrace -o g -- python3 tools/gemm_bench.py 30 > "$OUT/gtrace.log" 2>&1
+find /tmp/gtrace -name "*kernel_stats.csv" -exec cp {} "$OUT/roofline_kernel_stats.csv" \;
+python tools/roofline_rocprof.py profiles/$R /tmp/gtrace > "$OUT/roofline_rocprof_print.txt" 2>&1
+cp profiles/$R/roofline_rocprof.json "$OUT/roofline_rocprof.json"
+python tools/ktrace.py /tmp/gtrace > "$OUT/roofline_kernel_trace.txt" 2>&1
 # 1. the bench line (default flags: N=1, cpu_baseline, roofline with the PMC traffic just measured, dropout-0.1 line)
 timeout 900 python bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.txt"
 # 1b. the multi-rank path on this one device (two ranks on cuda:0, gloo for the all-reduce: RCCL refuses two ranks per device)
@@ -22,10 +28,6 @@ FC_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 30 --warmup 5
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trace -o bench -- python3 bench.py --no-cpu-baseline --no-dropout-line --no-roofline --no-extra-legs --steps 30 --warmup 5 > "$OUT/trace.log" 2>&1
 python tools/prof_summary.py /tmp/trace 35 40 > "$OUT/bench_summary.txt" 2>&1
 find /tmp/trace -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
-# 2b. the roofline kernel alone: device-side duration to compare with roofline.us_per_launch (HIP events inside bench.py)
-GEMM_SHAPES="$ROOF" timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gtrace -o g -- python3 tools/gemm_bench.py 30 > "$OUT/gtrace.log" 2>&1
-find /tmp/gtrace -name "*kernel_stats.csv" -exec cp {} "$OUT/roofline_kernel_stats.csv" \;
-python tools/ktrace.py /tmp/gtrace > "$OUT/roofline_kernel_trace.txt" 2>&1
 # 2c. every GEMM shape of a layer + the non-GEMM kernels, stand-alone (device-side durations)
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/gall -o g -- python3 tools/gemm_bench.py 20 > /dev/null 2>&1; python tools/ktrace.py /tmp/gall > "$OUT/gemm_shapes_ktrace.txt" 2>&1
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/kb -o g -- python3 tools/kernel_bench.py 20 > /dev/null 2>&1; KTRACE_BYNAME=1 python tools/ktrace.py /tmp/kb > "$OUT/kernels_ktrace.txt" 2>&1
