@@ -163,6 +163,12 @@ __global__ void __launch_bounds__(64 * AF_WAVES) k_attn_fwd_mfma(const bf16_t* _
 }
 
 // ======================================================================== backward
+#ifdef FC_PROBES
+__device__ long long* g_ab_stamps = nullptr;      // tools build: s_memtime stamps of workgroup 0 of each body ([body][wave][64])
+#define AB_STAMP(body, k) do { long long* sp_ = g_ab_stamps; if (sp_ && bh == 0 && lane == 0) sp_[(body) * 512 + wave * 64 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AB_STAMP(body, k) do {} while (0)
+#endif
 // Two bodies, each with two tiles (56 KB for N = 197) in LDS so that two workgroups share a CU, one workgroup per (batch, head)
 // and body:
 //   k_attn_bwd_dq : K, V tiles in LDS; Q / dO / O fragments straight from global; waves split the query blocks
@@ -183,7 +189,10 @@ __device__ __forceinline__ float dot8(const bf16x8& a, const bf16x8& b) {
 // Register blocking: a wave works on a PAIR of 16-row blocks (32 queries in the dQ body, 32 keys in the dK/dV body) at a time, so
 // every K / V (Q / dO) fragment read from LDS feeds two MFMAs instead of one: half the LDS reads per MFMA of the one-block form
 // (the LDS port, not the matrix pipe, bounded that form), and twice the independent MFMA chains per step to cover their latency.
-template <int NF, int U, int NW>
+// PIPE (U == 1): software pipeline over the key pairs: the S^T / dP^T products of pair ss + 1 are issued BEFORE the exponent,
+// the packing and the dQ products of pair ss, so that the matrix pipe works on the next pair's scores while the VALU turns this pair's
+// into dS -- two independent chains per wave instead of one (read -> MFMA -> exp -> pack -> MFMA).
+template <int NF, int U, int NW, int PIPE = 0, bool EARLY = false>
 __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N,
                                                  int H, float scale) {
@@ -197,15 +206,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
   const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
   const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
-  stage_tile<NP, 64 * NW>(Ks, base + Dm, D3, N, tid);
-  stage_tile<NP, 64 * NW>(Vs, base + 2 * Dm, D3, N, tid);
-  __syncthreads();
-  bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
-  for (int qp = wave; qp < NF / U; qp += NW) {           // query group: rows 16 U qp .. 16 U (qp + 1) - 1
-    if (qp * 16 * U >= N) break;
-    bf16x8 qf[U][2], dof[U][2];
-    float dl[U], lq[U];
-    int qrow[U];
+  AB_STAMP(0, 0);
+  bf16x8 qf[U][2], dof[U][2];
+  float dl[U], lq[U];
+  int qrow[U];
+  auto fragments = [&](int qp) {     // the query group's Q / dO fragments, delta = rowsum(dO * O) and lse, straight from global
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       qrow[u] = (U * qp + u) * 16 + cl;
@@ -221,11 +226,56 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
       dl[u] = acc;
       lq[u] = qrow[u] < N ? lse[((size_t)b * H + h) * N + qrow[u]] * 1.4426950408889634f : 1e30f;   // log2 units, like sc2
     }
+  };
+  // EARLY: the first group's fragments are requested BEFORE the K / V staging (one memory round trip for both, as in the forward kernel),
+  // and a later group's right after the previous group's pair loop, ahead of its stores
+  if (EARLY && wave * 16 * U < N) fragments(wave);
+  stage_tile<NP, 64 * NW>(Ks, base + Dm, D3, N, tid);
+  stage_tile<NP, 64 * NW>(Vs, base + 2 * Dm, D3, N, tid);
+  __syncthreads();
+  AB_STAMP(0, 1);
+  bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
+  for (int qp = wave; qp < NF / U; qp += NW) {           // query group: rows 16 U qp .. 16 U (qp + 1) - 1
+    if (qp * 16 * U >= N) break;
+    AB_STAMP(0, 2 + 4 * (qp / NW));
+    if (!EARLY) fragments(qp);
     f32x4 dq[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int db = 0; db < 4; ++db) dq[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    AB_STAMP(0, 3 + 4 * (qp / NW) + (dl[0] == 123.456f));      // (the comparison makes the stamp wait for the fragments)
+    if (PIPE && U == 1) {
+      f32x4 st[2], dpt[2];
+      auto scores = [&](int ss, f32x4 (&st_)[2], f32x4 (&dpt_)[2]) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          st_[hh] = (f32x4){0.f, 0.f, 0.f, 0.f}; dpt_[hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            st_[hh] = MFMA(row_frag(Ks, (2 * ss + hh) * 16, ks, lane), qf[0][ks], st_[hh]);
+            dpt_[hh] = MFMA(row_frag(Vs, (2 * ss + hh) * 16, ks, lane), dof[0][ks], dpt_[hh]);
+          }
+        }
+      };
+      scores(0, st, dpt);
+#pragma unroll 1
+      for (int ss = 0; ss < NF / 2; ++ss) {
+        f32x4 stn[2], dptn[2];
+        const int sn = ss + 1 < NF / 2 ? ss + 1 : ss;      // (the last iteration recomputes its own pair: branch-free, result unused)
+        scores(sn, stn, dptn);
+        f32x4 ds[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) ds[hh][x] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[hh][x], sc2, -lq[0])) * (dpt[hh][x] - dl[0]);
+        const bf16x8 bfg = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dq[0][db] = MFMA(tr_frag(Ks, 32 * ss, db * 16, lane), bfg, dq[0][db]);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) { st[hh] = stn[hh]; dpt[hh] = dptn[hh]; }
+      }
+    } else
 #pragma unroll 1
     for (int ss = 0; ss < NF / 2; ++ss) {                  // key pair: keys 32 ss .. 32 ss + 31
       bf16x8 kf[2][2], vf[2][2];
@@ -257,18 +307,27 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
         for (int u = 0; u < U; ++u) dq[u][db] = MFMA(kt, bfg[u], dq[u][db]);   // dQ^T[d = 16db+4g+x][q = cl]
       }
     }
+    AB_STAMP(0, 4 + 4 * (qp / NW) + (dq[0][0][0] == 123.456f));
+    uint2 pk[U][4];
+    bf16_t* prow[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      prow[u] = qrow[u] < N ? dbase + (size_t)qrow[u] * D3 + 4 * g : nullptr;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) pk[u][db] = make_uint2(f2bf2(dq[u][db][0] * scale, dq[u][db][1] * scale), f2bf2(dq[u][db][2] * scale, dq[u][db][3] * scale));
+    }
+    if (EARLY && qp + NW < NF / U && (qp + NW) * 16 * U < N) fragments(qp + NW);
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (qrow[u] < N) {   // a lane owns 4 consecutive head dims of its query row: 8-byte stores
-        bf16_t* p = dbase + (size_t)qrow[u] * D3 + 4 * g;
+      if (prow[u]) {       // a lane owns 4 consecutive head dims of its query row: 8-byte stores
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
-          *(uint2*)(p + db * 16) = make_uint2(f2bf2(dq[u][db][0] * scale, dq[u][db][1] * scale), f2bf2(dq[u][db][2] * scale, dq[u][db][3] * scale));
+        for (int db = 0; db < 4; ++db) *(uint2*)(prow[u] + db * 16) = pk[u][db];
       }
   }
+  AB_STAMP(0, 20);
 }
 
-template <int NF, int U, int NW>
+template <int NF, int U, int NW, int PIPE = 0, bool EARLY = false>
 __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                   const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N,
                                                   int H, float scale) {
@@ -284,6 +343,18 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
   const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
   const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
   const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
+  AB_STAMP(1, 0);
+  bf16x8 kfb[U][2], vfb[U][2];
+  int krow[U];
+  auto fragments = [&](int kp) {     // the key group's K / V fragments straight from global
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      krow[u] = (U * kp + u) * 16 + cl;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { kfb[u][ks] = gfrag(base + Dm, D3, krow[u], N, ks, g); vfb[u][ks] = gfrag(base + 2 * Dm, D3, krow[u], N, ks, g); }
+    }
+  };
+  if (EARLY && wave * 16 * U < N) fragments(wave);      // ahead of the staging: one memory round trip for both
   stage_tile<NP, 64 * NW>(Qs, base, D3, N, tid);
   // stage dO and form delta = rowsum(dO * O): a row's 8 chunks sit in 8 consecutive lanes
   {
@@ -314,22 +385,59 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
     }
   }
   __syncthreads();
+  AB_STAMP(1, 1);
   bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
   for (int kp = wave; kp < NF / U; kp += NW) {           // key group: keys 16 U kp .. 16 U (kp + 1) - 1
     if (kp * 16 * U >= N) break;
-    bf16x8 kfb[U][2], vfb[U][2];
-    int krow[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      krow[u] = (U * kp + u) * 16 + cl;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) { kfb[u][ks] = gfrag(base + Dm, D3, krow[u], N, ks, g); vfb[u][ks] = gfrag(base + 2 * Dm, D3, krow[u], N, ks, g); }
-    }
+    AB_STAMP(1, 2 + 4 * (kp / NW));
+    if (!EARLY) fragments(kp);
     f32x4 dv[U][4], dk[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int db = 0; db < 4; ++db) { dv[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[u][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    AB_STAMP(1, 3 + 4 * (kp / NW) + (kfb[0][0][0] == 12345 && vfb[0][1][0] == 12345));
+    if (PIPE && U == 1) {
+      f32x4 sa[2], dpa[2];
+      auto scores = [&](int qp, f32x4 (&sa_)[2], f32x4 (&dpa_)[2]) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          sa_[hh] = (f32x4){0.f, 0.f, 0.f, 0.f}; dpa_[hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            sa_[hh] = MFMA(row_frag(Qs, (2 * qp + hh) * 16, ks, lane), kfb[0][ks], sa_[hh]);
+            dpa_[hh] = MFMA(row_frag(Ds, (2 * qp + hh) * 16, ks, lane), vfb[0][ks], dpa_[hh]);
+          }
+        }
+      };
+      scores(0, sa, dpa);
+#pragma unroll 1
+      for (int qp = 0; qp < NF / 2; ++qp) {
+        f32x4 san[2], dpan[2];
+        const int qn = qp + 1 < NF / 2 ? qp + 1 : qp;
+        scores(qn, san, dpan);
+        f32x4 P[2], dS[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const float4 l4 = *(const float4*)(lse_s + (2 * qp + hh) * 16 + 4 * g), d4 = *(const float4*)(del_s + (2 * qp + hh) * 16 + 4 * g);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dlv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[hh][x], sc2, -lv[x]));
+            P[hh][x] = pr;
+            dS[hh][x] = pr * (dpa[hh][x] - dlv[x]);
+          }
+        }
+        const bf16x8 pa = pack8(P[0], P[1]), dsa = pack8(dS[0], dS[1]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          dv[0][db] = MFMA(tr_frag(Ds, 32 * qp, db * 16, lane), pa, dv[0][db]);
+          dk[0][db] = MFMA(tr_frag(Qs, 32 * qp, db * 16, lane), dsa, dk[0][db]);
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) { sa[hh] = san[hh]; dpa[hh] = dpan[hh]; }
+      }
+    } else
 #pragma unroll 1
     for (int qp = 0; qp < NF / 2; ++qp) {                  // query pair: rows 32 qp .. 32 qp + 31
       bf16x8 qf[2][2], df[2][2];
@@ -376,18 +484,30 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int bh, const bf16
         }
       }
     }
+    AB_STAMP(1, 4 + 4 * (kp / NW) + (dv[0][0][0] == 123.456f && dk[0][0][0] == 123.456f));
+    uint2 pkk[U][4], pkv[U][4];
+    bf16_t* prow[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      prow[u] = krow[u] < N ? dbase + (size_t)krow[u] * D3 + Dm + 4 * g : nullptr;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        pkk[u][db] = make_uint2(f2bf2(dk[u][db][0] * scale, dk[u][db][1] * scale), f2bf2(dk[u][db][2] * scale, dk[u][db][3] * scale));
+        pkv[u][db] = make_uint2(f2bf2(dv[u][db][0], dv[u][db][1]), f2bf2(dv[u][db][2], dv[u][db][3]));
+      }
+    }
+    if (EARLY && kp + NW < NF / U && (kp + NW) * 16 * U < N) fragments(kp + NW);
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (krow[u] < N) {   // a lane owns 4 consecutive head dims of its key row: 8-byte stores
-        bf16_t* pk = dbase + (size_t)krow[u] * D3 + Dm + 4 * g;
-        bf16_t* pv = dbase + (size_t)krow[u] * D3 + 2 * Dm + 4 * g;
+      if (prow[u]) {       // a lane owns 4 consecutive head dims of its key row: 8-byte stores
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          *(uint2*)(pk + db * 16) = make_uint2(f2bf2(dk[u][db][0] * scale, dk[u][db][1] * scale), f2bf2(dk[u][db][2] * scale, dk[u][db][3] * scale));
-          *(uint2*)(pv + db * 16) = make_uint2(f2bf2(dv[u][db][0], dv[u][db][1]), f2bf2(dv[u][db][2], dv[u][db][3]));
+          *(uint2*)(prow[u] + db * 16) = pkk[u][db];
+          *(uint2*)(prow[u] + Dm + db * 16) = pkv[u][db];
         }
       }
   }
+  AB_STAMP(1, 20);
 }
 
 // ======================================================================== fused backward (N > 64): EXPERIMENT, tools build only
@@ -418,19 +538,33 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, in
 // U = 16-row blocks a wave owns, NW = waves per workgroup: <2, 4> = 32-row register blocking at 2 waves per SIMD (207 VGPRs);
 // <1, 8> = 16-row blocking under 128 VGPRs, 4 waves per SIMD (twice the LDS fragment reads per MFMA, twice the waves to hide the
 // MFMA -> exponent -> MFMA dependency chain behind)
-template <int NF, int U, int NW>
+template <int NF, int U, int NW, int PIPE = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 2) k_attn_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int half = B * H;
-  if ((int)blockIdx.x < half) attn_bwd_dq_body<NF, U, NW>(smem, blockIdx.x, qkv, o, dout, lse, dqkv, B, N, H, scale);
-  else attn_bwd_dkv_body<NF, U, NW>(smem, blockIdx.x - half, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  if ((int)blockIdx.x < half) attn_bwd_dq_body<NF, U, NW, (PIPE & 1), (PIPE & 4) != 0>(smem, blockIdx.x, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  else attn_bwd_dkv_body<NF, U, NW, (PIPE & 2), (PIPE & 4) != 0>(smem, blockIdx.x - half, qkv, o, dout, lse, dqkv, B, N, H, scale);
 }
-template <int NF, int U = 2, int NW = 4>
+#ifdef FC_PROBES
+static long long* g_ab_stamps_host = nullptr;
+extern "C" int fc_dbg_attn_stamps(long long* out1024) {      // tools build: the stamps of the last backward launch (call after a synchronise)
+  if (!g_ab_stamps_host) return -1;
+  return hipMemcpy(out1024, g_ab_stamps_host, 1024 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+template <int NF, int U = 2, int NW = 4, int PIPE = 0>
 static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, bf16_t* dqkv, int B, int N, int H, float scale,
                       hipStream_t s) {
   const int lds_q = 2 * 16 * NF * 128, lds_kv = 2 * 16 * NF * 128 + 2 * 16 * NF * 4;
-  auto kb = k_attn_bwd<NF, U, NW>;
+#ifdef FC_PROBES
+  static long long* stamps = nullptr;
+  if (fc_knob("FC_ATTN_STAMPS", 0)) {
+    if (!stamps) { FC_CHECK_HIP(hipMalloc(&stamps, 1024 * sizeof(long long))); FC_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ab_stamps), &stamps, sizeof(stamps))); g_ab_stamps_host = stamps; }
+    FC_CHECK_HIP(hipMemsetAsync(stamps, 0, 1024 * sizeof(long long), s));
+  }
+#endif
+  auto kb = k_attn_bwd<NF, U, NW, PIPE>;
   const int lds = lds_kv > lds_q ? lds_kv : lds_q;
   static bool done = false;
   if (!done) {
@@ -470,6 +604,16 @@ int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, con
   // (a wave-uniform branch, 1 / 14 of the work) 33.0 us: neither kept.
   // FC_ATTN_BWD_U1=0 (tools build) restores the 32-row form.
   static const int u1 = fc_knob("FC_ATTN_BWD_U1", 1);
+  static const int pipe = fc_knob("FC_ATTN_BWD_PIPE", 0);      // software-pipelined key / query-pair loop (round 5)
+  if (pipe && u1 && pick_nf(N) == 14) {                       // bits: 1 the dQ half's pair loop pipelined, 2 the dK/dV half's, 4 early fragment requests
+    switch (pipe) {
+      case 1: return launch_bwd<14, 1, 8, 1>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+      case 2: return launch_bwd<14, 1, 8, 2>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+      case 3: return launch_bwd<14, 1, 8, 3>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+      case 4: return launch_bwd<14, 1, 8, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+      case 5: return launch_bwd<14, 1, 8, 5>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+    }
+  }
   switch (pick_nf(N)) {
     case 2: return u1 ? launch_bwd<2, 1, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s) : launch_bwd<2>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
     case 4: return u1 ? launch_bwd<4, 1, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s) : launch_bwd<4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
