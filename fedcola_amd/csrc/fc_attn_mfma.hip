@@ -179,6 +179,23 @@ __device__ __forceinline__ bf16x8 gfrag(const bf16_t* __restrict__ base, long ld
   if (row < N) v = *(const uint4*)(base + (size_t)row * ld + ks * 32 + g * 8);
   return *(bf16x8*)&v;
 }
+// branch-free form: the row is clamped and the fragment of a row past N zeroed afterwards (no exec-mask branch between the loads)
+__device__ __forceinline__ bf16x8 gfrag_nb(const bf16_t* __restrict__ base, long ld, int row, int N, int ks, int g) {
+  const int rc = row < N ? row : N - 1;
+  return *(const bf16x8*)(base + (size_t)rc * ld + ks * 32 + g * 8);
+}
+// the same loads as inline asm: hipcc sinks plain loads towards their first use (below an LDS-DMA issue, where waiting for them would drain the
+// DMA); these stay where they are written.  The compiler does not count them: the consumer waits with frag_wait<K>() (K = younger VMEM operations).
+__device__ __forceinline__ void gload16_asm(bf16x8& dst, const bf16_t* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gload4_asm(float& dst, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+template <int K>
+__device__ __forceinline__ void frag_wait(bf16x8 (&a)[2], bf16x8 (&b)[2], bf16x8 (&c)[2], float& l) {
+  asm volatile("s_waitcnt vmcnt(%7)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1]), "+v"(l) : "n"(K) : "memory");
+}
+__device__ __forceinline__ bf16x8 zero_past(bf16x8 v, bool ok) {
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return ok ? v : z;
+}
 __device__ __forceinline__ float dot8(const bf16x8& a, const bf16x8& b) {
   float s = 0.f;
 #pragma unroll
@@ -210,30 +227,48 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
   bf16x8 qf[U][2], dof[U][2];
   float dl[U], lq[U];
   int qrow[U];
-  auto fragments = [&](int qp) {     // the query group's Q / dO fragments, delta = rowsum(dO * O) and lse, straight from global
+  bf16x8 of_[U][2];
+  float lraw[U];
+  auto frag_issue = [&](int qp) {    // the query group's Q / dO / O fragments and lse: loads only, branch-free, nothing consumed
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       qrow[u] = (U * qp + u) * 16 + cl;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[u][ks] = gfrag_nb(base, D3, qrow[u], N, ks, g);
+        dof[u][ks] = gfrag_nb(dobase, Dm, qrow[u], N, ks, g);
+        of_[u][ks] = gfrag_nb(obase, Dm, qrow[u], N, ks, g);
+      }
+      lraw[u] = lse[((size_t)b * H + h) * N + (qrow[u] < N ? qrow[u] : N - 1)];
+    }
+  };
+  auto frag_finish = [&]() {         // delta = rowsum(dO * O), lse in log2 units, rows past N zeroed
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = qrow[u] < N;
       float acc = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        qf[u][ks] = gfrag(base, D3, qrow[u], N, ks, g);
-        dof[u][ks] = gfrag(dobase, Dm, qrow[u], N, ks, g);
-        acc += dot8(dof[u][ks], gfrag(obase, Dm, qrow[u], N, ks, g));
+        qf[u][ks] = zero_past(qf[u][ks], ok);
+        dof[u][ks] = zero_past(dof[u][ks], ok);
+        acc += dot8(dof[u][ks], of_[u][ks]);
       }
       acc += __shfl_xor(acc, 16, 64);
       acc += __shfl_xor(acc, 32, 64);                                    // delta[q = cl]
       dl[u] = acc;
-      lq[u] = qrow[u] < N ? lse[((size_t)b * H + h) * N + qrow[u]] * 1.4426950408889634f : 1e30f;   // log2 units, like sc2
+      lq[u] = ok ? lraw[u] * 1.4426950408889634f : 1e30f;                // log2 units, like sc2
     }
   };
-  // EARLY: the first group's fragments are requested BEFORE the K / V staging (one memory round trip for both, as in the forward kernel),
-  // and a later group's right after the previous group's pair loop, ahead of its stores
-  if (EARLY && wave * 16 * U < N) fragments(wave);
+  auto fragments = [&](int qp) { frag_issue(qp); frag_finish(); };
+  // EARLY: the first group's fragments are requested BEFORE the K / V staging (one memory round trip for both, as in the forward kernel)
+  // and consumed after it; a later group's right after the previous group's pair loop, ahead of its stores
+  if (EARLY && wave * 16 * U < N) frag_issue(wave);
+  if (EARLY) __builtin_amdgcn_sched_barrier(0);
   stage_tile<NP, 64 * NW>(Ks, base + Dm, D3, N, tid);
   stage_tile<NP, 64 * NW>(Vs, base + 2 * Dm, D3, N, tid);
   __syncthreads();
   AB_STAMP(0, 1);
+  if (EARLY && wave * 16 * U < N) frag_finish();
   bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
   for (int qp = wave; qp < NF / U; qp += NW) {           // query group: rows 16 U qp .. 16 U (qp + 1) - 1
     if (qp * 16 * U >= N) break;
@@ -316,13 +351,176 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int bh, const bf16_
 #pragma unroll
       for (int db = 0; db < 4; ++db) pk[u][db] = make_uint2(f2bf2(dq[u][db][0] * scale, dq[u][db][1] * scale), f2bf2(dq[u][db][2] * scale, dq[u][db][3] * scale));
     }
-    if (EARLY && qp + NW < NF / U && (qp + NW) * 16 * U < N) fragments(qp + NW);
+    const bool more = EARLY && qp + NW < NF / U && (qp + NW) * 16 * U < N;
+    if (more) frag_issue(qp + NW);
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (prow[u]) {       // a lane owns 4 consecutive head dims of its query row: 8-byte stores
 #pragma unroll
         for (int db = 0; db < 4; ++db) *(uint2*)(prow[u] + db * 16) = pk[u][db];
       }
+    if (more) frag_finish();
+  }
+  AB_STAMP(0, 20);
+}
+
+// ---- chunk-pipelined form of the dQ body (round 5): K and V go to LDS by LDS-DMA (buffer_load ... lds: no registers, the swizzle is applied on
+// the SOURCE side -- lane l of 1-KB piece p fetches the logical chunk that physical slot (row 8p + l / 8, l % 8) holds), one 32-key chunk per wave
+// and key pair in the order the pair loop consumes them, behind counted s_waitcnt vmcnt(6 - ss): pair ss starts when ITS chunk has landed while
+// the chunks of the later pairs are still in flight.  Every LDS read of the loop is inline asm (hipcc puts s_waitcnt vmcnt(0) in front of any LDS
+// access it sees while an LDS-DMA is in flight, fc_mfma_dev.h) with explicit lgkmcnt fences that tie the fragments.
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+__device__ __forceinline__ bf16x8 row_frag_asm(const char* T, int rb, int ks, int lane) {
+  bf16x8 f;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const char*)(T + at_off(rb + (lane & 15), ks * 4 + (lane >> 4)))) : "memory");
+  return f;
+}
+__device__ __forceinline__ void tr_frag_asm(const char* T, int r0, int cb, int lane, s16x4& lo, s16x4& hi) {
+  int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  int col = cb + 4 * p, c = col >> 3, cbyte = (col & 7) * 2;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const char*)(T + at_off(r0 + 4 * g + q, c) + cbyte)) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const char*)(T + at_off(r0 + 16 + 4 * g + q, c) + cbyte)) : "memory");
+}
+__device__ __forceinline__ void fence8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
+}
+__device__ __forceinline__ void fence_tr(s16x4 (&lo)[4], s16x4 (&hi)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])::"memory");
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t attn_rsrc(const bf16_t* p, long bytes) {
+  unsigned long long base = (unsigned long long)p;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+// one 1-KB piece (8 tile rows) of a [N][64] slice -> its place in the swizzled tile; rows past N read as zero (out-of-range offset)
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t r, char* T, int piece, long ld, int N, int lane) {
+  const int row = piece * 8 + (lane >> 3), c = (lane & 7) ^ hd(row);
+  const unsigned vo = row < N ? (unsigned)((row * ld + c * 8) * 2) : 0x80000000u;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (attn_lds_ptr_t)(T + piece * 1024), 16, vo, 0, 0, 0);
+}
+template <int K> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); }
+__device__ __forceinline__ void wait_vm_dyn(int k) {      // k in 0 .. 6
+  switch (k) {
+    case 0: wait_vm<0>(); break; case 1: wait_vm<1>(); break; case 2: wait_vm<2>(); break; case 3: wait_vm<3>(); break;
+    case 4: wait_vm<4>(); break; case 5: wait_vm<5>(); break; default: wait_vm<6>(); break;
+  }
+}
+
+template <int NF, int NW>
+__device__ __forceinline__ void attn_bwd_dq_dma(char* smem, int bh, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N,
+                                                int H, float scale) {
+  static_assert(NW == 8 && NF == 14, "8 waves: waves 0-3 fetch K, waves 4-7 V, one 1-KB piece per wave and 32-key chunk, 7 chunks");
+  constexpr int NP = 16 * NF;
+  char* Ks = smem;
+  char* Vs = smem + NP * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, cl = lane & 15;
+  const float sc2 = scale * 1.4426950408889634f;
+  const int b = bh / H, h = bh % H;
+  const long D3 = 3L * H * 64, Dm = (long)H * 64;
+  const bf16_t* base = qkv + (size_t)b * N * D3 + h * 64;
+  const bf16_t* obase = o + (size_t)b * N * Dm + h * 64;
+  const bf16_t* dobase = dout + (size_t)b * N * Dm + h * 64;
+  AB_STAMP(0, 0);
+  bf16x8 qf[2], dof[2], of_[2];
+  float dl, lq, lraw;
+  int qrow;
+  auto frag_issue = [&](int qp) {
+    qrow = qp * 16 + cl;
+    const int rc = qrow < N ? qrow : N - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      gload16_asm(qf[ks], base + (size_t)rc * D3 + ks * 32 + g * 8);
+      gload16_asm(dof[ks], dobase + (size_t)rc * Dm + ks * 32 + g * 8);
+      gload16_asm(of_[ks], obase + (size_t)rc * Dm + ks * 32 + g * 8);
+    }
+    gload4_asm(lraw, lse + ((size_t)b * H + h) * N + rc);
+  };
+  auto frag_finish = [&]() {
+    const bool ok = qrow < N;
+    float acc = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = zero_past(qf[ks], ok);
+      dof[ks] = zero_past(dof[ks], ok);
+      acc += dot8(dof[ks], of_[ks]);
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    dl = acc;
+    lq = ok ? lraw * 1.4426950408889634f : 1e30f;
+  };
+  frag_issue(wave);                                      // OLDER than the DMA below: consumed behind vmcnt(7) while all seven chunks fly
+  __builtin_amdgcn_sched_barrier(0);                     // (hipcc otherwise sinks some of these loads below the DMA: waiting for them would drain it)
+  {
+    const bool isv = wave >= 4;
+    const __amdgpu_buffer_rsrc_t r = attn_rsrc(base + (isv ? 2 : 1) * Dm, ((long)(N - 1) * D3 + 64) * 2);
+    char* T = isv ? Vs : Ks;
+#pragma unroll
+    for (int c = 0; c < NF / 2; ++c) dma_piece(r, T, 4 * c + (wave & 3), D3, N, lane);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  frag_wait<NF / 2>(qf, dof, of_, lraw);                 // the seven younger operations are this wave's DMA pieces
+  frag_finish();
+  bf16_t* dbase = dqkv + (size_t)b * N * D3 + h * 64;
+  for (int qp = wave; qp < NF; qp += NW) {
+    if (qp * 16 >= N) break;
+    const bool first = qp == wave;
+    if (!first) { AB_STAMP(0, 2 + 4 * (qp / NW)); }
+    f32x4 dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    AB_STAMP(0, 3 + 4 * (qp / NW) + (dl == 123.456f));
+#pragma unroll 1
+    for (int ss = 0; ss < NF / 2; ++ss) {
+      if (first) {                                       // this pair's chunk has landed (this wave's piece: vmcnt; everyone's: the barrier)
+        wait_vm_dyn(NF / 2 - 1 - ss);
+        __builtin_amdgcn_s_barrier();
+        if (ss == 0) { AB_STAMP(0, 1); }
+      }
+      bf16x8 kf[4], vf[4];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { kf[2 * hh + ks] = row_frag_asm(Ks, (2 * ss + hh) * 16, ks, lane); vf[2 * hh + ks] = row_frag_asm(Vs, (2 * ss + hh) * 16, ks, lane); }
+      fence8(kf, vf);
+      f32x4 st[2], dpt[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        st[hh] = (f32x4){0.f, 0.f, 0.f, 0.f}; dpt[hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { st[hh] = MFMA(kf[2 * hh + ks], qf[ks], st[hh]); dpt[hh] = MFMA(vf[2 * hh + ks], dof[ks], dpt[hh]); }
+      }
+      s16x4 tlo[4], thi[4];                              // the transposed K fragments are requested before the exponent work that hides them
+#pragma unroll
+      for (int db = 0; db < 4; ++db) tr_frag_asm(Ks, 32 * ss, db * 16, lane, tlo[db], thi[db]);
+      f32x4 ds[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ds[hh][x] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[hh][x], sc2, -lq)) * (dpt[hh][x] - dl);
+      const bf16x8 bfg = pack8(ds[0], ds[1]);
+      fence_tr(tlo, thi);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        bf16x8 kt;
+        kt[0] = tlo[db][0]; kt[1] = tlo[db][1]; kt[2] = tlo[db][2]; kt[3] = tlo[db][3];
+        kt[4] = thi[db][0]; kt[5] = thi[db][1]; kt[6] = thi[db][2]; kt[7] = thi[db][3];
+        dq[db] = MFMA(kt, bfg, dq[db]);
+      }
+    }
+    AB_STAMP(0, 4 + 4 * (qp / NW) + (dq[0][0] == 123.456f));
+    uint2 pk[4];
+    bf16_t* prow = qrow < N ? dbase + (size_t)qrow * D3 + 4 * g : nullptr;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) pk[db] = make_uint2(f2bf2(dq[db][0] * scale, dq[db][1] * scale), f2bf2(dq[db][2] * scale, dq[db][3] * scale));
+    const bool more = qp + NW < NF && (qp + NW) * 16 < N;
+    if (more) frag_issue(qp + NW);
+    if (prow) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) *(uint2*)(prow + db * 16) = pk[db];
+    }
+    if (more) { frag_wait<0>(qf, dof, of_, lraw); frag_finish(); }
   }
   AB_STAMP(0, 20);
 }
@@ -543,8 +741,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) k_attn_bwd(const bf16_t* __re
                                                               const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int half = B * H;
-  if ((int)blockIdx.x < half) attn_bwd_dq_body<NF, U, NW, (PIPE & 1), (PIPE & 4) != 0>(smem, blockIdx.x, qkv, o, dout, lse, dqkv, B, N, H, scale);
-  else attn_bwd_dkv_body<NF, U, NW, (PIPE & 2), (PIPE & 4) != 0>(smem, blockIdx.x - half, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  // the dK/dV workgroups are the longer ones (two accumulators per pair): they are dispatched FIRST, so that when the grid does not fit the chip
+  // in one round (B = 64: 768 workgroups, 512 resident) the short dQ workgroups form the partial second round (PIPE & 16: the former order)
+  const bool dq_first = (PIPE & 16) != 0;
+  const int blk = blockIdx.x;
+  const bool is_dq = dq_first ? blk < half : blk >= half;
+  const int bh = (is_dq == dq_first) ? blk : blk - half;
+  if (is_dq) {
+    if constexpr ((PIPE & 8) != 0) attn_bwd_dq_dma<NF, NW>(smem, bh, qkv, o, dout, lse, dqkv, B, N, H, scale);
+    else attn_bwd_dq_body<NF, U, NW, (PIPE & 1), (PIPE & 4) != 0>(smem, bh, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  }
+  else attn_bwd_dkv_body<NF, U, NW, (PIPE & 2), (PIPE & 4) != 0>(smem, bh, qkv, o, dout, lse, dqkv, B, N, H, scale);
 }
 #ifdef FC_PROBES
 static long long* g_ab_stamps_host = nullptr;
@@ -604,16 +811,21 @@ int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, con
   // (a wave-uniform branch, 1 / 14 of the work) 33.0 us: neither kept.
   // FC_ATTN_BWD_U1=0 (tools build) restores the 32-row form.
   static const int u1 = fc_knob("FC_ATTN_BWD_U1", 1);
-  static const int pipe = fc_knob("FC_ATTN_BWD_PIPE", 0);      // software-pipelined key / query-pair loop (round 5)
-  if (pipe && u1 && pick_nf(N) == 14) {                       // bits: 1 the dQ half's pair loop pipelined, 2 the dK/dV half's, 4 early fragment requests
+#ifdef FC_PROBES      // round 5's measured variants of the N = 197 kernel (profiles/r05/attn_bwd_pipeline.txt): none beat the default, tools build only
+  static const int pipe = fc_knob("FC_ATTN_BWD_PIPE", 0);
+  if (pipe && u1 && pick_nf(N) == 14) {                       // bits: 1 the dQ half's pair loop pipelined, 2 the dK/dV half's, 4 early fragment requests, 8 the dQ half chunk-pipelined behind LDS-DMA
     switch (pipe) {
       case 1: return launch_bwd<14, 1, 8, 1>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
       case 2: return launch_bwd<14, 1, 8, 2>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
       case 3: return launch_bwd<14, 1, 8, 3>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
       case 4: return launch_bwd<14, 1, 8, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
       case 5: return launch_bwd<14, 1, 8, 5>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+      case 12: if (N > 112) return launch_bwd<14, 1, 8, 12>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);      // 8: the dQ half chunk-pipelined behind LDS-DMA
+               break;
+      case 16: return launch_bwd<14, 1, 8, 16>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);                     // 16: dQ workgroups first (rounds 2-4)
     }
   }
+#endif
   switch (pick_nf(N)) {
     case 2: return u1 ? launch_bwd<2, 1, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s) : launch_bwd<2>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
     case 4: return u1 ? launch_bwd<4, 1, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s) : launch_bwd<4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
