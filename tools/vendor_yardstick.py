@@ -26,7 +26,13 @@ bf = torch.bfloat16
 D, Hd = 384, 1536
 
 
-def ev_time(fn, reps, warm=3):
+SEG = [0]
+
+
+def ev_time(fn, reps, warm=3, label=None):
+    # a marker kernel in front of every timed leg: `KTRACE_SPLIT=spin tools/ktrace.py DIR` then prints one segment per leg, in this order
+    torch.cuda._sleep(2000); SEG[0] += 1
+    if label: print(f"#   segment {SEG[0]}: {label}")
     for i in range(warm): fn(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,11 +57,11 @@ def gemm_leg():
             As = [torch.randn(M, K, device=dev).to(bf) for _ in range(nset)]
             Ws = [(torch.randn((N, K) if kind == 0 else (K, N), device=dev) * K ** -0.5).to(bf) for _ in range(12)]
             Cs = [torch.empty(M, N, device=dev, dtype=bf) for _ in range(nset)]
-            ours = ev_time(lambda i: _lib.check(L.fc_k_gemm(1, kind, 1, 1, P(As[i % nset]), P(Ws[i % 12]), P(Cs[i % nset]), M, N, K, None, 0, sp)), reps)
+            ours = ev_time(lambda i: _lib.check(L.fc_k_gemm(1, kind, 1, 1, P(As[i % nset]), P(Ws[i % 12]), P(Cs[i % nset]), M, N, K, None, 0, sp)), reps, label=f'ours   {name} rows {M}')
             if kind == 0:
-                vend = ev_time(lambda i: torch.matmul(As[i % nset], Ws[i % 12].t(), out=Cs[i % nset]), reps)
+                vend = ev_time(lambda i: torch.matmul(As[i % nset], Ws[i % 12].t(), out=Cs[i % nset]), reps, label=f'vendor {name} rows {M}')
             else:
-                vend = ev_time(lambda i: torch.matmul(As[i % nset], Ws[i % 12], out=Cs[i % nset]), reps)
+                vend = ev_time(lambda i: torch.matmul(As[i % nset], Ws[i % 12], out=Cs[i % nset]), reps, label=f'vendor {name} rows {M}')
             fl = 2.0 * M * N * K
             print(f"  {name:10s} {M:6d} {N:5d} {K:5d} | {ours:8.1f} {fl / ours / 1e6:7.1f} | {vend:9.1f} {fl / vend / 1e6:7.1f} | {vend / ours:5.2f}")
             del As, Ws, Cs
@@ -66,8 +72,8 @@ def gemm_leg():
             Co = [torch.empty(N1, N2, device=dev) for _ in range(4)]
             Cv = [torch.empty(N1, N2, device=dev, dtype=bf) for _ in range(4)]
             db = torch.empty(N1, device=dev)
-            ours = ev_time(lambda i: _lib.check(L.fc_k_dw(1, P(dY[i % nset]), P(X[i % nset]), P(Co[i % 4]), P(db), M, N1, N2, sp)), reps)
-            vend = ev_time(lambda i: torch.matmul(dY[i % nset].t(), X[i % nset], out=Cv[i % 4]), reps)
+            ours = ev_time(lambda i: _lib.check(L.fc_k_dw(2, P(dY[i % nset]), P(X[i % nset]), P(Co[i % 4]), P(db), M, N1, N2, sp)), reps, label=f'ours   {name} rows {M}')
+            vend = ev_time(lambda i: torch.matmul(dY[i % nset].t(), X[i % nset], out=Cv[i % 4]), reps, label=f'vendor {name} rows {M}')
             fl = 2.0 * M * N1 * N2
             print(f"  {name:10s} {M:6d} {N1:5d}x{N2:<5d}| {ours:8.1f} {fl / ours / 1e6:7.1f} | {vend:9.1f} {fl / vend / 1e6:7.1f} | {vend / ours:5.2f}   (ours: the entry point allocates and synchronises per call -- read OUR time from the kernel trace)")
             del dY, X, Co, Cv
