@@ -25,7 +25,7 @@ timeout 900 python bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.txt"
 # 1b. the multi-rank path on this one device (two ranks on cuda:0, gloo for the all-reduce: RCCL refuses two ranks per device)
 FC_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 30 --warmup 5 --no-roofline > "$OUT/bench_2ranks_one_device.json" 2> "$OUT/bench_2ranks_stderr.txt"
 # 2. kernel trace + stats of the same workload (35 steps)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trace -o bench -- python3 bench.py --no-cpu-baseline --no-dropout-line --no-roofline --no-extra-legs --steps 30 --warmup 5 > "$OUT/trace.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trace -o bench -- python3 bench.py --no-cpu-baseline --no-dropout-line --no-roofline --no-extra-legs --device-resident --steps 30 --warmup 5 > "$OUT/trace.log" 2>&1
 python tools/prof_summary.py /tmp/trace 35 40 > "$OUT/bench_summary.txt" 2>&1
 find /tmp/trace -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
 # 2c. every GEMM shape of a layer + the non-GEMM kernels, stand-alone (device-side durations)
@@ -41,7 +41,7 @@ done
 timeout 200 python tools/step_phases.py 40 2>/dev/null > "$OUT/step_phases.txt"
 # 4. whole-step fabric traffic (separate passes)
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "/tmp/step_$c" -o s -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-dropout-line --no-extra-legs > "$OUT/step_$c.log" 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "/tmp/step_$c" -o s -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-dropout-line --no-extra-legs --device-resident > "$OUT/step_$c.log" 2>&1
   python tools/pmc_sum.py "/tmp/step_$c" 5 > "$OUT/step_pmc_$c.txt" 2>&1
 done
 # 5. widened rows
@@ -55,7 +55,7 @@ timeout 300 python tools/aggregate_bench.py 8 10 2>/dev/null > "$OUT/aggregate_b
 timeout 200 python tools/tiny_step.py 50 2>/dev/null > "$OUT/tiny_step.txt"
 timeout 200 python tools/client_round_trace.py 2>/dev/null > "$OUT/client_round_trace.txt"
 if [ -f fedcola_amd/libfedcola_hip_probes.so ]; then
-  B2="python bench.py --no-cpu-baseline --no-roofline --no-dropout-line --no-extra-legs --steps 100 --warmup 10"
+  B2="python bench.py --no-cpu-baseline --no-roofline --no-dropout-line --no-extra-legs --steps 100 --warmup 10 --device-resident"
   ms() { grep -o '"ms_per_step": [0-9.]*' | tr '\n' ' '; }
   { echo "# ms per step, tools build, same box, two passes each (bench.py --steps 100 --warmup 10)"
     for i in 1 2; do
