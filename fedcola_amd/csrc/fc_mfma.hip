@@ -19,6 +19,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+
 #include "fc_kernels.h"
 #include "fc_mfma_dev.h"
 
@@ -594,6 +597,108 @@ __global__ void __launch_bounds__(256, 1) k_gemm_d64(GemmGroup g) {
   half_epilogue<EPI, TC, true, MT>(Cs, C, ldc, m0, n0, M, N, e, tid, 0, crs, prs, pre.bias, pre.rin0, pre.sc0);
 }
 
+// ======================================================================== split reduction ACROSS workgroups (round 5; EXPERIMENT, tools build only)
+// The same under-filled long-reduction launches (102 tiles of 18-24 k-steps at chain size), a third way: each output tile is computed by TWO
+// workgroups of the ordinary shape (128 x 128 tile, two 32-KB stages, 64 KB of LDS: two per CU beside anything else), each walking HALF of the
+// k-tiles.  The 64-row forms above either kept the k-chain (64-row tiles: twice the workgroups for the same time = twice the CU-slot time) or
+// bought the speed with LDS (ring: 72-96 KB).  This one halves the serial chain at the SAME CU-slot time: 204 workgroups x ~half the duration.
+// Exchange: a workgroup writes its partial accumulators (fp32, register order: 64 KB, coalesced) to a per-stream scratch, releases, and bumps
+// the tile's flag; the workgroup that finds the flag already bumped acquires, adds the other partial and runs the epilogue.  a + b == b + a
+// bit for bit, so the result does not depend on which half arrives last; it differs from the one-workgroup kernel's by the order of summation.
+// Measured (profiles/r05/gemm_splitk_cold.txt, gemm_splitk_in_step_ab.txt): 24.5 -> 19.2 us (fc2 forward) and 20-24 -> 15.3 us (fc1 / qkv dX) at chain
+// size, 24.3 -> 18.6 / 14.4 at the text tower's 2 048 rows, 30.6 -> 42.4 at the full batch -- and the B = 64 step 4.55 -> 4.70 ms (+3 %): 204
+// workgroups x 15-19 us is MORE workgroup-time than 102 x 24.5, and the step pays for workgroup-time, not for one kernel's latency.
+#ifdef FC_PROBES
+template <int BMODE, typename TC, int EPI>
+__global__ void __launch_bounds__(256, 2) k_gemm_sk(GemmGroup g, float* __restrict__ part, unsigned* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x (A 16 KB | B 16 KB); the epilogue image aliases buffer 0
+  constexpr int MT = 128, NI = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int N = g.N, K = g.K, tiles_n = g.tiles_n;
+  const int T = K / BK, Th = T >> 1;                               // the launcher checks K % (2 BK) == 0
+  const int id = xcd_remap(blockIdx.x, gridDim.x);                 // the two halves of a tile are neighbours: same XCD, same L2
+  const int ct = id >> 1, kh = id & 1;
+  const GemmProb& P = g.p[0];
+  const GemmEpi& e = P.e;
+  const int M = P.M;
+  const long ldc = P.ldc;
+  TC* C = (TC*)P.C;
+  const int m0 = (ct / tiles_n) * MT, n0 = (ct % tiles_n) * BN;
+  f32x4 acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Operand oa = make_operand_glds<KC>(P.A, P.lda, 0, M, K, wave, lane);
+  Operand ob = make_operand_glds<BMODE>(P.B, P.ldb, 0, N, K, wave, lane);
+  retarget_glds<KC>(oa, P.lda, m0, M, wave, lane, true);
+  retarget_glds<BMODE>(ob, P.ldb, n0, N, wave, lane, true);
+  const int k0 = kh * Th;
+#define SK_ISSUE(kt, b)                                                                \
+  do {                                                                                 \
+    char* dst = smem + (b) * 32768;                                                    \
+    stage_glds<KC>(oa, dst, (kt) * BK, K, wave, lane);                                 \
+    stage_glds<BMODE>(ob, dst + 16384, (kt) * BK, K, wave, lane);                      \
+  } while (0)
+  SK_ISSUE(k0, 0);
+#pragma unroll 1
+  for (int k = 0; k < Th; ++k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (k + 1 < Th) SK_ISSUE(k0 + k + 1, (k + 1) & 1);
+    tile_compute<KC, BMODE, NI>(smem + (k & 1) * 32768, acc, wm, wn, lane);
+  }
+#undef SK_ISSUE
+  // ---- hand the partial over, or take the other one.  Coherence by ACCESS, not by fence: the partial tiles are stored and loaded with the
+  // system-scope cache policy (sc0 sc1: written through to memory, read past the caches), the flag is an agent-scope atomic.  A release /
+  // acquire fence pair (__threadfence) costs a write-back of the XCD's whole L2 per wave here: 24 -> 53 us per launch, measured.
+  float* mine = part + ((size_t)ct * 2 + kh) * (MT * BN);
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine + ((i * 4 + j) * 256 + tid) * 4), "v"(acc[i][j]) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this thread's partial has reached memory ...
+  __shared__ unsigned arrived;
+  __builtin_amdgcn_s_barrier();                                    // ... and so has every other thread's, before the flag moves
+  if (tid == 0) arrived = __hip_atomic_fetch_add(flags + ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (arrived == 0) return;                                        // first of the two: the other half finishes the tile
+  EpiRegs pre;
+  if (EpiPre<EPI, TC>::on) epi_prefetch<EPI, TC, MT>(pre, ldc, m0, n0, M, N, e, tid);
+  const float* other = part + ((size_t)ct * 2 + (kh ^ 1)) * (MT * BN);
+  f32x4 o[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(o[i][j]) : "v"(other + ((i * 4 + j) * 256 + tid) * 4) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("" : "+v"(o[i][j]));                            // (ties the loaded registers behind the wait)
+      acc[i][j] += o[i][j];
+    }
+  if (tid == 0) __hip_atomic_store(flags + ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+  const long crows = (long)M + (e.patch_rows > 0 ? M / e.patch_rows + 2 : 0);
+  const __amdgpu_buffer_rsrc_t crs = make_store_rsrc((void*)C, crows * ldc * (long)sizeof(TC));
+  const __amdgpu_buffer_rsrc_t prs = make_store_rsrc(e.preact ? e.preact : (void*)C, crows * ldc * (long)sizeof(TC));
+  float* Cs = (float*)smem;
+  lds_barrier();
+  acc_to_lds_half<0, NI>(Cs, acc, wm, wn, lane);
+  lds_barrier();
+  half_epilogue<EPI, TC, true, MT>(Cs, C, ldc, m0, n0, M, N, e, tid, 0, crs, prs, pre.bias, pre.rin0, pre.sc0);
+  lds_barrier();
+  acc_to_lds_half<1, NI>(Cs, acc, wm, wn, lane);
+  lds_barrier();
+  half_epilogue<EPI, TC, true, MT>(Cs, C, ldc, m0, n0, M, N, e, tid, 1, crs, prs, pre.bias, pre.rin1, pre.sc1);
+}
+#endif      // FC_PROBES (split reduction across workgroups)
+
 // ======================================================================== grouped weight-gradient GEMM
 // All dW = dY^T . X products of a backward pass (every linear of every layer of both towers) in ONE launch, each output
 // tile owned by exactly one workgroup that walks the whole reduction: no split-K, no atomics, bitwise reproducible.
@@ -803,6 +908,50 @@ static int launch_gemm_deep(int kind, int ek, int stages, const GemmGroup& g, hi
 #undef GO_D
   return 1;
 }
+#ifdef FC_PROBES
+// per-(device, stream) scratch of the split-reduction form: partial tiles + one flag per tile (a stream runs one GEMM at a time)
+#define SK_MAX_TILES 512
+static std::mutex g_sk_mu;
+static std::map<std::pair<int, hipStream_t>, char*> g_sk_ws;
+static int sk_scratch(hipStream_t s, float** part, unsigned** flags) {
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  int dev = 0;
+  FC_CHECK_HIP(hipGetDevice(&dev));
+  char*& w = g_sk_ws[std::make_pair(dev, s)];
+  const size_t pbytes = (size_t)SK_MAX_TILES * 2 * BM * BN * sizeof(float);
+  if (!w) {                                                        // once per stream and process (allocates and zero-fills the flags)
+    FC_CHECK_HIP(hipMalloc((void**)&w, pbytes + SK_MAX_TILES * sizeof(unsigned)));
+    FC_CHECK_HIP(hipMemset(w + pbytes, 0, SK_MAX_TILES * sizeof(unsigned)));
+  }
+  *part = (float*)w;
+  *flags = (unsigned*)(w + pbytes);
+  return 0;
+}
+template <int BMo, typename TC, int EPI>
+static int launch_gemm_sk(const GemmGroup& g, hipStream_t s) {
+  const int lds = 65536;
+  auto kfn = k_gemm_sk<BMo, TC, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  float* part; unsigned* flags;
+  FC_TRY(sk_scratch(s, &part, &flags));
+  hipLaunchKernelGGL(kfn, dim3(2 * g.ntiles), dim3(256), lds, s, g, part, flags);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+static int launch_gemm_splitk(int kind, int ek, const GemmGroup& g, hipStream_t s) {
+  if (kind == FC_GEMM_NT) {
+    switch (ek) { case EPI_RES: return launch_gemm_sk<KC, bf16_t, EPI_RES>(g, s); case EPI_RES_SCALE: return launch_gemm_sk<KC, bf16_t, EPI_RES_SCALE>(g, s);
+                  case EPI_BIAS: return launch_gemm_sk<KC, bf16_t, EPI_BIAS>(g, s); }
+  } else if (kind == FC_GEMM_NN) {
+    if (ek == EPI_PLAIN) return launch_gemm_sk<KR, bf16_t, EPI_PLAIN>(g, s);
+  }
+  return 1;
+}
+#endif
 // process-wide form of the under-filled launches (fc_model_set_option FC_OPT_GEMM_FORM; tools build: FC_GEMM_MT64 / FC_GEMM_DEEP64):
 // 0 = 128-row tiles, 64 = 64-row tiles, 3 / 4 = 64-row tiles with a 3- / 4-stage ring
 static int g_gemm_form = 0;
@@ -852,6 +1001,21 @@ int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t 
     for (int i = 0; i < nprob; ++i) t128 += fc_cdiv(g.p[i].M, BM) * g.tiles_n;
     if (thr > 0 && t128 <= thr && gemm_has_mt64(kind, dtC, ek)) mt = 64;
   }
+#ifdef FC_PROBES
+  {
+    // ... or, when its reduction is long (K >= 1 024), computed by two workgroups per tile, half of the k-tiles each (tools build: FC_GEMM_SPLITK=1)
+    static const int sk_env = fc_knob("FC_GEMM_SPLITK", 0);
+    const bool sk = sk_env > 0;
+    const int t128 = fc_cdiv(g.p[0].M, BM) * g.tiles_n;
+    if (sk && nprob == 1 && dtC == FC_BF16 && t128 <= SK_MAX_TILES && g.K >= 1024 && (g.K % (2 * BK)) == 0 && gemm_has_mt64(kind, dtC, ek) &&
+        g.p[0].e.patch_rows == 0) {
+      GemmGroup d = g;
+      d.tiles0 = t128; d.ntiles = t128; d.p[1] = d.p[0];
+      const int r = launch_gemm_splitk(kind, ek, d, s);
+      if (r <= 0) return r;
+    }
+  }
+#endif
   {
     // ... and when its reduction is long (K >= 1 024: fc2 forward, fc1 / qkv dX of a chain) into 64-row tiles with a deep staging ring, one per workgroup
     static const int deep_env = fc_knob("FC_GEMM_DEEP64", 0);      // stages (3 | 4), 0 = off (stand-alone 24.4 -> 15.2 us, in the step +2 ... +6 %: off)
