@@ -467,8 +467,8 @@ def launch_ranks(a, argv):
            "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in child.stdout:
-        sys.stdout.write(line)
+    for line in child.stdout:      # the contract is ONE JSON line on stdout: anything else a rank or the launcher printed goes to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
         sys.stdout.flush()
     return child.wait()
 
@@ -549,6 +549,11 @@ def main():
     if in_job and world != a.gpus:
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
+    # stdout carries the one JSON line and nothing else: file descriptor 1 is pointed at stderr for the rest of the run (RCCL's version banner,
+    # gloo's connection messages and the runtime's notices are written to fd 1 by native code), the line goes to a duplicate of the original
+    line_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     cpu_base = None
     if world == 1 and not a.no_cpu_baseline:
         cpu_base = cpu_baseline(a.batch, Args.seq_len, Args.vocab_size)      # before any GPU call in this process
@@ -855,7 +860,7 @@ def main():
             out["roofline"] = gemm_roofline()
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=line_out, flush=True)
     if world > 1:
         if comm_c is not None:
             comm_c.close()
