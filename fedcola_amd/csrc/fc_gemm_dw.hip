@@ -327,7 +327,53 @@ __device__ __forceinline__ void dws_kstep(unsigned lb, unsigned po, const DwKeys
 #define DWS_SLOT 32768   // one stage: 4 images of [32 k][128 cols]
 // NSLOT: stages of the ring (4: 128 KB of LDS, three stages in flight; 3: 96 KB, two in flight -- leaves room for a 64-KB GEMM workgroup of a
 // backward chain on the same CU)
-template <bool OPT, int NSLOT>
+// ---- flag-synchronised ring (FLAGS = true; round 5): no workgroup barrier inside the main loop.  A loader wave publishes "stage s has landed"
+// by writing s + 1 to ready[slot][loader] (after its counted vmcnt), a consumer wave reports "done reading the slot" by adding 1 to done[slot];
+// the loader refills a slot once its done counter has reached 8 x (uses so far).  The eight consumer waves are no longer forced through the
+// read -> MFMA phases of a stage together: the two waves of a SIMD drift apart and one's fragment reads run under the other's MFMAs.
+// LDS words behind the ring: ready[NSLOT][2], done[NSLOT].  All flag accesses are inline asm (a compiler-visible LDS access beside an LDS-DMA in
+// flight gets an s_waitcnt vmcnt(0) in front of it).
+__device__ __forceinline__ unsigned dwf_ld(unsigned addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void dwf_ld2_issue(unsigned long long& v, unsigned addr) { asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void dwf_st(unsigned addr, unsigned v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void dwf_add1(unsigned addr) { asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory"); }
+// a k-step that also requests the NEXT stage's ready words beside its second half of fragment reads (they land under the first 12 MFMAs) and
+// releases its slot as soon as its last fragment read has returned
+template <int KS>
+__device__ __forceinline__ void dws_kstep_flags(unsigned lb, unsigned po, const DwKeys& kx, f32x4 (&acc)[4][6], float (&cs4)[4], bool colsum,
+                                                unsigned next_ready_addr, unsigned long long& next_ready, unsigned done_addr, bool lane0) {
+  bf16x8 af[4], b0[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af[i] = dw_frag<KS>(lb, kx.a[i] | po);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) b0[j] = dw_frag<KS>(lb, kx.b[j] | po);
+  frag_fence(af);
+  frag_fence3(b0);
+  bf16x8 b1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) b1[j] = dw_frag<KS>(lb, kx.b[3 + j] | po);
+  dwf_ld2_issue(next_ready, next_ready_addr);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], af[i], acc[i][j], 0, 0, 0);
+  if (colsum) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs4[i] = dws_sum8(af[i], cs4[i]);
+  }
+  frag_fence3(b1);                                           // lgkmcnt(0): every read of this slot (and the ready words) has returned
+  asm volatile("" : "+v"(next_ready));
+  if (lane0) dwf_add1(done_addr);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][3 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], af[i], acc[i][3 + j], 0, 0, 0);
+}
+template <bool OPT, int NSLOT, bool FLAGS = false>
 __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restrict__ probs, int nprob, FcAdamW o_) {
   const FcAdamW o = fc_adamw_resolve(o_);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -381,6 +427,23 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
     }                                                                                                                        \
   } while (0)
     // rows past K read as zeros (descriptor bounds), so stages past S may be issued freely: the counted wait stays uniform
+    if (FLAGS) {
+      const unsigned fl0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem + NSLOT * DWS_SLOT;
+      const unsigned ready0 = fl0 + 4u * (unsigned)lw, done0 = fl0 + 8u * NSLOT;
+      __builtin_amdgcn_s_barrier();                            // the flag words are zero (all ten waves; the only barrier before the epilogue)
+#pragma unroll 1
+      for (int d = 0; d < NSLOT - 1; ++d) DWS_ISSUE(d);
+      for (int st = 0; st < S; ++st) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * (NSLOT - 2)) : "memory");   // stage st has landed (NSLOT - 2 younger stages fly on)
+        dwf_st(ready0 + 8u * (unsigned)(st % NSLOT), (unsigned)st + 1u);
+        if (st >= 1) {                                         // the slot of stage st - 1 is free once all eight consumer waves have left it
+          const unsigned want = 8u * (unsigned)((st - 1) / NSLOT + 1), da = done0 + 4u * (unsigned)((st - 1) % NSLOT);
+          while (dwf_ld(da) < want) __builtin_amdgcn_s_sleep(1);
+        }
+        DWS_ISSUE(st + NSLOT - 1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
     DWS_ISSUE(0); DWS_ISSUE(1);
     if (NSLOT == 4) DWS_ISSUE(2);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * (NSLOT - 2)) : "memory");   // 16 per stage and wave: stage 0 has landed
@@ -391,6 +454,7 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
       __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the over-issued stages land before the epilogue reuses the LDS
+    }
 #undef DWS_ISSUE
   } else {
     unsigned lb;
@@ -409,11 +473,31 @@ __global__ void __launch_bounds__(640) k_gemm_dw_spec(const FcTnProblem* __restr
       }
     }
     const bool colsum = do_colsum && wn == 0;
+    if (FLAGS) {
+      const unsigned fl0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem + NSLOT * DWS_SLOT;
+      if (tid < 3 * NSLOT) dwf_st(fl0 + 4u * (unsigned)tid, 0u);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                            // flags zeroed
+      const unsigned done0 = fl0 + 8u * NSLOT;
+      unsigned long long rd = 0;
+      for (int st = 0; st < S; ++st) {
+        const unsigned slot = (unsigned)(st % NSLOT), want = (unsigned)st + 1u;
+        // both loader waves' halves of this stage have landed?  (the words were requested during the previous stage; poll if not yet)
+        unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rd), r1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rd >> 32));
+        while (st == 0 || r0 < want || r1 < want) {
+          r0 = dwf_ld(fl0 + 8u * slot); r1 = dwf_ld(fl0 + 8u * slot + 4u);
+          if (r0 >= want && r1 >= want) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        dws_kstep_flags<0>(lb, slot * DWS_SLOT, kx, acc, cs4, colsum, fl0 + 8u * (unsigned)((st + 1) % NSLOT), rd, done0 + 4u * slot, lane == 0);
+      }
+    } else {
     __builtin_amdgcn_s_barrier();                              // stage 0 has landed
     for (int st = 0; st < S; ++st) {
       dws_kstep<0>(lb, (unsigned)((st % NSLOT) * DWS_SLOT), kx, acc, cs4, colsum);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of this slot is done before it is refilled
       __builtin_amdgcn_s_barrier();
+    }
     }
   }
   lds_barrier();                                               // loaders: vmcnt(0) above; nobody touches the ring any more
@@ -496,6 +580,10 @@ int fc_gemm_dw_wide_tiles(const FcTnProblem& p, int* tiles_n) {
   *tiles_n = fc_cdiv(p.N, DW_BN);
   return fc_cdiv(p.M, BM) * *tiles_n;
 }
+static bool dw_flags() {
+  static const int v = fc_knob("FC_DW_FLAGS", 0);      // the flag-synchronised ring (no barrier in the main loop)
+  return v != 0;
+}
 int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hipStream_t s, const FcAdamW* opt, int form_arg) {
   if (nprob <= 0 || total_tiles <= 0) return 0;
   const int lds = 2 * DW_STAGE;
@@ -527,6 +615,18 @@ int fc_gemm_dw_wide(const FcTnProblem* probs_dev, int nprob, int total_tiles, hi
       }
       if (opt) hipLaunchKernelGGL((k_gemm_dw_spec<true, 3>), dim3(total_tiles), dim3(640), lds3, s, probs_dev, nprob, *opt);
       else hipLaunchKernelGGL((k_gemm_dw_spec<false, 3>), dim3(total_tiles), dim3(640), lds3, s, probs_dev, nprob, FcAdamW());
+#ifdef FC_PROBES      // measured: 245.6 vs 230.9 us per launch in the step, step +0.5 % (profiles/r05/dw_flags_*.txt) -- the ring is ingest-bound, not lockstep-bound
+    } else if (dw_flags()) {
+      const int ldsf = lds + 64;      // + the ring's flag words
+      static bool donef = false;
+      if (!donef) {
+        FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
+        FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_dw_spec<true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
+        donef = true;
+      }
+      if (opt) hipLaunchKernelGGL((k_gemm_dw_spec<true, 4, true>), dim3(total_tiles), dim3(640), ldsf, s, probs_dev, nprob, *opt);
+      else hipLaunchKernelGGL((k_gemm_dw_spec<false, 4, true>), dim3(total_tiles), dim3(640), ldsf, s, probs_dev, nprob, FcAdamW());
+#endif
     } else {
       if (opt) hipLaunchKernelGGL((k_gemm_dw_spec<true, 4>), dim3(total_tiles), dim3(640), lds, s, probs_dev, nprob, *opt);
       else hipLaunchKernelGGL((k_gemm_dw_spec<false, 4>), dim3(total_tiles), dim3(640), lds, s, probs_dev, nprob, FcAdamW());
