@@ -76,6 +76,7 @@ struct fc_model {
   // weight gradients are launched in chunks (every few layers) on their own stream, under the rest of the backward
   mutable hipStream_t dws = nullptr;
   mutable hipEvent_t ev_dw_in = nullptr, ev_dw_in2[3] = {nullptr, nullptr, nullptr}, ev_dw_out = nullptr, ev_dw_prev = nullptr;
+  mutable hipEvent_t ev_dw_last = nullptr, ev_zero = nullptr;      // the last chunk when it runs on a chain's stream; the step's zero-fills on the text stream
   // second micro-batch of the image tower
   mutable hipStream_t mbs[3] = {nullptr, nullptr, nullptr};      // micro-batch chains 1..3 (chain 0 runs on the caller's stream)
   mutable hipEvent_t ev_mb_join[3] = {nullptr, nullptr, nullptr};
@@ -92,6 +93,8 @@ struct fc_model {
     }
     if (ev_dw_out) (void)hipEventDestroy(ev_dw_out);
     if (ev_dw_prev) (void)hipEventDestroy(ev_dw_prev);
+    if (ev_dw_last) (void)hipEventDestroy(ev_dw_last);
+    if (ev_zero) (void)hipEventDestroy(ev_zero);
     if (cap) (void)hipStreamDestroy(cap);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -1124,6 +1127,8 @@ static int ensure_side(const fc_model* m, hipStream_t caller) {
     }
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_out, hipEventDisableTiming));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_prev, hipEventDisableTiming));
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_dw_last, hipEventDisableTiming));
+    FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_zero, hipEventDisableTiming));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     FC_CHECK_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   }
@@ -1571,6 +1576,7 @@ static int tower_reparam_grads(const Ctx& c, int i, float* grads) {
 struct LateDw {
   bool pending = false;
   bool fused = false;             // fused optimizer: no segment waits for a chunk; the caller waits for ev_dw_out once, at the end
+  bool wait_last = false;         // ... and for ev_dw_last: the last chunk was launched on a chain's stream AFTER the caller's stream joined the chains
   std::vector<char> late_seg;     // per segment: its gradient is written by the last chunk
 };
 // covered (optional, out): per segment, 1 when this backward OVERWRITES the segment's gradient with plain stores (grouped weight-gradient
@@ -1679,6 +1685,7 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
     const bool cls_head_first = run0 && nimg > 1 && !(w.feat_out || m->tw[0].task == FC_TASK_RTV);
     if (cls_head_first) FC_TRY(tower_backward(c, w, 0, d_out_img, grads, PH_HEAD));
     FC_TRY(chains_fork(m, s, ch, n));
+    bool joined = false;                             // the caller's stream already waits for every chain (early join below)
     Ctx cx[4], cf_ = c;
     hipStream_t extra[3];
     int nextra = 0;
@@ -1797,10 +1804,27 @@ static int backward_impl(const fc_model* m, const float* params, const void* wc,
       if (kt >= 0 && ch[kt].s == m->dws && last_knob)
         for (int k = 0; k < n && !last_on; ++k)
           if (ch[k].tower == 0 && ch[k].s != s) last_on = ch[k].s;
-      FC_TRY(flush_dw(cf_, last_narrow, last_on));
+      // Round 5 experiment (FC_DW_EARLY_JOIN=1, tools build): the caller's stream joins the chains WITHOUT waiting for the last chunk, so that what
+      // follows on it (the LayerNorm reduction, the optimizer's remainder: ~70 us of launches) runs beside the chunk instead of behind it, and
+      // fc_client_step waits for ev_dw_last at its very end.  Measured (profiles/r05/tail_overlap_*.txt): the two kernels do run under the chunk
+      // (next step starts 31 us after it instead of 81), but the chunk itself starts ~40 us later behind the extra event records and runs 6 %
+      // longer beside them: 4.432 vs 4.427 ms per step -- a wash, off.
+      static const int early_knob = fc_knob("FC_DW_EARLY_JOIN", 0);
+      if (last_on && late && late->fused && early_knob) {      // the chains' join events are recorded BEFORE the chunk is enqueued on one of them ...
+        for (int k = 0; k < n; ++k)
+          if (ch[k].s != s) FC_CHECK_HIP(hipEventRecord(ch[k].join, ch[k].s));
+        joined = true;
+      }
+      FC_TRY(flush_dw(cf_, last_narrow, last_on));             // (its own dependencies stay direct: one event hop, as before)
+      if (joined) {                                            // ... and waited for after it: the caller's stream does not wait for the chunk
+        for (int k = 0; k < n; ++k)
+          if (ch[k].s != s) FC_CHECK_HIP(hipStreamWaitEvent(s, ch[k].join, 0));
+        FC_CHECK_HIP(hipEventRecord(m->ev_dw_last, last_on));
+        late->wait_last = true;
+      }
     }
     FC_STREAM_EV(3, m->side); FC_STREAM_EV(4, m->mbs[0]); FC_STREAM_EV(5, s);
-    FC_TRY(chains_join(s, ch, n));
+    if (!joined) FC_TRY(chains_join(s, ch, n));
   }
   if (covered) {
     covered->assign(m->segs.size(), 0);
@@ -2125,13 +2149,30 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
       if (!sg.trainable || strstr(sg.name, "aux_weight")) plain = false;
     if (!plain) return FC_STEP_DECLINED;
   }
-  if (know_cover) {
-    for (const std::pair<int64_t, int64_t>& r : m->zero_runs) FC_CHECK_HIP(hipMemsetAsync(grads + r.first, 0, sizeof(float) * (size_t)r.second, s));
-  } else {
-    FC_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->total, s));
+  // The zero-fills (four small launches, ~7 us each back to back) go to the text tower's stream, which has slack in the forward, instead of
+  // standing in front of the image chains; that stream first waits for the caller's (the previous step's optimizer read these gradients), and
+  // the caller's stream waits for it again behind the forward (FC_ZERO_SIDE=0, tools build: on the caller's stream as before)
+  hipStream_t zs = s;
+  static const int zero_side = fc_knob("FC_ZERO_SIDE", 1);
+  if (both && m->dt == FC_BF16 && zero_side && !chain_schedule()) {
+    FC_TRY(ensure_side(m, s));
+    if (m->side && m->side != s) {
+      FC_CHECK_HIP(hipEventRecord(m->ev_zero, s));
+      FC_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_zero, 0));
+      zs = m->side;
+    }
   }
-  FC_CHECK_HIP(hipMemsetAsync(lossbuf + 1, 0, sizeof(float), s));
+  if (know_cover) {
+    for (const std::pair<int64_t, int64_t>& r : m->zero_runs) FC_CHECK_HIP(hipMemsetAsync(grads + r.first, 0, sizeof(float) * (size_t)r.second, zs));
+  } else {
+    FC_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->total, zs));
+  }
+  FC_CHECK_HIP(hipMemsetAsync(lossbuf + 1, 0, sizeof(float), zs));
   FC_TRY(forward_impl(m, params, wc, img, ids, B, n_txt, both ? 1 : 0, droppath, workspace, workspace_bytes, nullptr, nullptr, s, w));
+  if (zs != s) {      // (the forward joined the text stream already; this names the dependency of the loss and the backward on the zero-fills)
+    FC_CHECK_HIP(hipEventRecord(m->ev_zero, zs));
+    FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_zero, 0));
+  }
   m->last = LastFwd{workspace, B, w.n_txt, both ? 1 : 0, droppath, ids};
   FC_PHASE(1);
   const float *d0 = nullptr, *d1 = nullptr;
@@ -2189,6 +2230,7 @@ static int client_step_impl(const fc_model_t* m, float* params, float* grads, fl
   if (fused) {
     FC_TRY(adamw_rest(m, fseg, fo, s));
     if (late.pending) FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_out, 0));
+    if (late.wait_last) FC_CHECK_HIP(hipStreamWaitEvent(s, m->ev_dw_last, 0));
   } else if (late.pending) {   // everything that does not wait for the last weight-gradient chunk, then the chunk, then the rest
     FC_TRY(adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, s, fuse_shadow ? (bf16_t*)wc : nullptr,
                         &late.late_seg, 0));
