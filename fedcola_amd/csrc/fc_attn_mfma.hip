@@ -737,7 +737,7 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, in
 // <1, 8> = 16-row blocking under 128 VGPRs, 4 waves per SIMD (twice the LDS fragment reads per MFMA, twice the waves to hide the
 // MFMA -> exponent -> MFMA dependency chain behind)
 template <int NF, int U, int NW, int PIPE = 0>
-__global__ void __launch_bounds__(64 * NW, NW / 2) k_attn_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+__global__ void __launch_bounds__(64 * NW, (NW >= 16 ? 4 : NW / 2)) k_attn_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int half = B * H;
@@ -823,6 +823,8 @@ int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, con
       case 12: if (N > 112) return launch_bwd<14, 1, 8, 12>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);      // 8: the dQ half chunk-pipelined behind LDS-DMA
                break;
       case 16: return launch_bwd<14, 1, 8, 16>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);                     // 16: dQ workgroups first (rounds 2-4)
+      case 32: return launch_bwd<14, 1, 16, 0>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);                     // 32: 16 waves per workgroup, one 16-row block per wave
+      case 36: return launch_bwd<14, 1, 16, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);                     //     ... with the fragments requested ahead of the staging
     }
   }
 #endif
