@@ -745,8 +745,19 @@ __global__ void __launch_bounds__(64 * NW, (NW >= 16 ? 4 : NW / 2)) k_attn_bwd(c
   // in one round (B = 64: 768 workgroups, 512 resident) the short dQ workgroups form the partial second round (PIPE & 16: the former order)
   const bool dq_first = (PIPE & 16) != 0;
   const int blk = blockIdx.x;
-  const bool is_dq = dq_first ? blk < half : blk >= half;
-  const int bh = (is_dq == dq_first) ? blk : blk - half;
+  bool is_dq;
+  int bh;
+  if constexpr ((PIPE & 64) != 0) {
+    // paired mapping: the two workgroups of a (batch, head) run on the SAME XCD (workgroup b runs on XCD b % 8), eight dispatch slots apart, so
+    // the operands one of them has pulled through the fabric are L2 hits for the other: groups of 16 = {dK/dV of 8 heads, dQ of the same 8}
+    const int p = blk >> 4, r = blk & 15;
+    is_dq = r >= 8;
+    bh = p * 8 + (r & 7);
+    if (bh >= half) return;
+  } else {
+    is_dq = dq_first ? blk < half : blk >= half;
+    bh = (is_dq == dq_first) ? blk : blk - half;
+  }
   if (is_dq) {
     if constexpr ((PIPE & 8) != 0) attn_bwd_dq_dma<NF, NW>(smem, bh, qkv, o, dout, lse, dqkv, B, N, H, scale);
     else attn_bwd_dq_body<NF, U, NW, (PIPE & 1), (PIPE & 4) != 0>(smem, bh, qkv, o, dout, lse, dqkv, B, N, H, scale);
@@ -778,7 +789,8 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, co
     FC_CHECK_HIP(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
   }
-  hipLaunchKernelGGL(kb, dim3(B * H * 2), dim3(64 * NW), lds, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
+  const int grid = (PIPE & 64) ? ((B * H + 7) / 8) * 16 : B * H * 2;
+  hipLaunchKernelGGL(kb, dim3(grid), dim3(64 * NW), lds, s, qkv, o, dout, lse, dqkv, B, N, H, scale);
   FC_LAUNCH_CHECK();
   return 0;
 }
@@ -823,6 +835,7 @@ int fc_attn_bwd_mfma(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, con
       case 12: if (N > 112) return launch_bwd<14, 1, 8, 12>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);      // 8: the dQ half chunk-pipelined behind LDS-DMA
                break;
       case 16: return launch_bwd<14, 1, 8, 16>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);                     // 16: dQ workgroups first (rounds 2-4)
+      case 64: return launch_bwd<14, 1, 8, 64>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);                     // 64: both workgroups of a (batch, head) on one XCD, dispatched together
       case 32: return launch_bwd<14, 1, 16, 0>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);                     // 32: 16 waves per workgroup, one 16-row block per wave
       case 36: return launch_bwd<14, 1, 16, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);                     //     ... with the fragments requested ahead of the staging
     }
