@@ -463,14 +463,49 @@ def launch_ranks(a, argv):
         print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible (set FC_BENCH_ONE_DEVICE=1 to validate the multi-rank path on one "
               f"device)", file=sys.stderr)
         return 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    cmd, env_add = launch_command(a.gpus, argv, free_port())
+    # a CHILD process, started before this one has made any GPU call (device_count() above does not initialise the runtime); never an
+    # exec of this process: on this pool replacing a process that holds the GPU takes the machine down
+    child = subprocess.Popen(cmd, env=dict(os.environ, **env_add), stdout=subprocess.PIPE, text=True)
     for line in child.stdout:      # the contract is ONE JSON line on stdout: anything else a rank or the launcher printed goes to stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line)
         sys.stdout.flush()
     return child.wait()
+
+
+def launch_command(gpus, argv, port, python=None, script=None):
+    """The one place that knows how `--gpus N` becomes N ranks: (argv of the child, environment variables added to this process's).  The
+    launcher (launch_ranks) runs it, `--dry-run` prints it, tests/test_bench_dry_run.py compares the two."""
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    # dmabuf IPC is the only kind the host driver supports: without it RCCL fails with hipIpcGetMemHandle: invalid argument
+    return cmd, {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+
+
+def negotiate_comm(dist, make_comm, flag_device, skip=False):
+    """The C-ABI RCCL communicator for the timed aggregation, or a recorded reason why not -- decided TOGETHER: if any rank fails to create
+    it, every rank closes its own and the run continues on torch.distributed's all-reduce (RCCL as well) with `cabi_comm_error` in the line.
+    Returns (comm or None, error string or None).  make_comm() -> object with .close(); it may raise."""
+    import torch
+    if skip:
+        return None, None
+    comm, err = None, None
+    try:
+        comm = make_comm()
+    except Exception as e:                                         # keep the run: the torch.distributed path is RCCL as well
+        err = f"{type(e).__name__}: {e}"[:300]
+    ok = torch.tensor([0 if comm is None else 1], device=flag_device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                      # every rank takes the same path
+    if int(ok) == 0 and comm is not None:
+        comm.close()
+        comm, err = None, "another rank could not create the C-ABI communicator"
+    return comm, err
+
+
+def aggregate_path_name(world, comm, backend):
+    if world == 1:
+        return "none (1 client)"
+    return "C ABI fc_aggregate: HIP blend + ncclAllReduce" if comm is not None else f"HIP blend + torch.distributed.all_reduce ({backend})"
 
 
 def client_plan(world, cpr):
@@ -498,8 +533,10 @@ def dry_run(a):
                               dtype="f32", op="sum", pre_scaled_by="closed-form weights of the sequential blend (fedcola_amd/aggregate.py)",
                               ring_one_link_ms=(round(2 * (world - 1) / world * msg / 153e9 * 1e3, 2) if world > 1 else 0.0),
                               direct_all_links_ms=(round(2 * (world - 1) / world * msg / (153e9 * max(world - 1, 1)) * 1e3, 2) if world > 1 else 0.0)),
-               launch=(["python", "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", "<free port>",
-                        "bench.py", "--gpus", str(world), "--steps", str(a.steps), "--warmup", str(a.warmup)] if world > 1 else ["python", "bench.py"]),
+               launch=(launch_command(world, ["--gpus", str(world), "--steps", str(a.steps), "--warmup", str(a.warmup)], "<free port>", python="python",
+                                      script="bench.py")[0] if world > 1 else ["python", "bench.py"]),
+               launch_env=(launch_command(world, [], 0)[1] if world > 1 else {}),
+               launch_how="child process (subprocess.Popen) started before the launcher touches the GPU; never exec",
                batch_feed=("device-resident" if a.device_resident else "pinned host memory -> DevicePrefetcher (H2D inclusive)"))
     print(json.dumps(out), flush=True)
     return 0
@@ -643,20 +680,15 @@ def main():
         torch.manual_seed(1)                                               # the global model is identical on every rank
         global_model = create_model("mome_small_patch16", False, args=args, num_classes=[None, None], modalities=["img", "txt"],
                                     tasks=["rtv", "rtv"]).to(dev)
-        comm_c = None
-        cabi_error = None
-        if not (one_device and os.environ.get("FC_BENCH_BACKEND", "gloo") == "gloo"):     # RCCL refuses two ranks on one device
-            from fedcola_amd.comm import Comm
-            try:
-                comm_c = Comm.from_torch_dist()
-            except Exception as e:                                         # keep the run: the torch.distributed path is RCCL as well
-                cabi_error = f"{type(e).__name__}: {e}"[:300]
-            ok = torch.tensor([0 if comm_c is None else 1], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                      # every rank takes the same path
-            if int(ok) == 0 and comm_c is not None:
-                comm_c.close()
-                comm_c = None
-                cabi_error = "another rank could not create the C-ABI communicator"
+        from fedcola_amd.comm import Comm
+
+        def make_comm():
+            if os.environ.get("FC_BENCH_INJECT_COMM_FAILURE"):             # tests/test_gpu_bench.py: the fallback line (every rank fails, as a
+                raise RuntimeError("injected failure (FC_BENCH_INJECT_COMM_FAILURE)")   # missing librccl would; from_torch_dist is collective)
+            return Comm.from_torch_dist()
+        # RCCL refuses two ranks on one device: the one-device validation run (gloo) has no C-ABI communicator unless a failure is injected
+        skip = one_device and os.environ.get("FC_BENCH_BACKEND", "gloo") == "gloo" and "FC_BENCH_INJECT_COMM_FAILURE" not in os.environ
+        comm_c, cabi_error = negotiate_comm(dist, make_comm, dev, skip=skip)
         comm = comm_c if a.agg == "cabi" else None
 
     agg_state = {}
@@ -834,14 +866,19 @@ def main():
                    last_loss=round(loss, 4), enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3),
                    aggregate_ms=round((dt - t_steps) * 1e3, 3), allreduce_bytes=(4 * n if world > 1 else 0),
                    per_rank_ms_per_step=[round(x / (a.steps * cpr) * 1e3, 3) for x in per_rank],
-                   aggregate_path=("none (1 client)" if world == 1 else ("C ABI fc_aggregate: HIP blend + ncclAllReduce" if comm is not None else
-                                   "HIP blend + torch.distributed.all_reduce (" + dist.get_backend() + ")")))
+                   aggregate_path=aggregate_path_name(world, comm, dist.get_backend() if world > 1 else None))
         if world > 1:
             agg_s = max(dt - t_steps, 1e-9)
             # ring all-reduce moves 2 (N-1)/N of the buffer through every link; GB/s per rank of payload = the figure xGMI is judged by
             out["aggregate_GBps"] = round(4 * n / agg_s / 1e9, 2)
             out["allreduce_bus_GBps"] = round(2 * (world - 1) / world * 4 * n / agg_s / 1e9, 2)
             out.update(selfcheck)
+            out["rccl_world"] = dist.get_world_size()                     # ranks the process group (backend below) was formed over
+            out["dist_backend"] = dist.get_backend()
+            try:
+                out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001
+                out["rccl_version"] = f"unavailable: {e}"[:100]
             if cabi_error:
                 out["cabi_comm_error"] = cabi_error
             # what answers SURVEY 8(e)'s ring-vs-direct question from this one line: the message, the time, and the RCCL knobs in force

@@ -99,31 +99,7 @@ class CreamflClient(FedavgClient):
 
     def _segmented_step(self, st, img, ids, labels, B, n_txt, dp, ws, lossbuf):
         """A local step composed from forward / criterion / backward / per-segment AdamW (step counts differ between parameters)."""
-        model, L = self.model, _lib.lib()
-        dev = st["dev"]
-        st["grads"].zero_()
-        i = 0 if self.modality == "img" else 1
-        if self.modality == "img+txt":
-            D = model.embed_dim
-            oi, ot = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
-            check(L.fc_forward(model._handle.h, ptr(model.flat), ptr(model._wc_or_flat()), ptr(img), ptr(ids), B, n_txt, 1, ptr(dp), ptr(ws),
-                               ws.numel(), ptr(oi), ptr(ot), _lib.stream_ptr()))
-            da, db = torch.empty_like(oi), torch.empty_like(ot)
-            scratch = torch.empty(L.fc_contrastive_scratch_floats(B), device=dev)
-            from ..criterions import contrastive_tau
-            check(L.fc_contrastive_loss_fwd_bwd(ptr(oi), ptr(ot), B, D, contrastive_tau(), ptr(scratch), scratch.numel(), ptr(lossbuf), ptr(da),
-                                                ptr(db), _lib.stream_ptr()))
-            d0, d1 = da, db
-        else:
-            C_ = model.num_classes[i]
-            lg = torch.empty(B, C_, device=dev)
-            check(L.fc_forward(model._handle.h, ptr(model.flat), ptr(model._wc_or_flat()), ptr(img), ptr(ids), B, n_txt, 0, ptr(dp), ptr(ws),
-                               ws.numel(), ptr(lg) if i == 0 else None, ptr(lg) if i == 1 else None, _lib.stream_ptr()))
-            dl = torch.empty_like(lg)
-            check(L.fc_ce_loss_fwd_bwd(ptr(lg), ptr(labels), B, C_, ptr(lossbuf), ptr(dl), _lib.stream_ptr()))
-            d0, d1 = (dl, None) if i == 0 else (None, dl)
-        check(L.fc_backward(model._handle.h, ptr(model.flat), ptr(model._wc_or_flat()), ptr(d0), ptr(d1), ptr(st["grads"]), ptr(ws), ws.numel(),
-                            _lib.stream_ptr()))
+        self._forward_backward(st, img, ids, labels, B, n_txt, dp, ws, lossbuf)
         self._adam_segs(st, st["seg_train"])
 
     def _after_epoch(self, e, st, step):

@@ -100,11 +100,14 @@ class FedavgClient(BaseClient):
         model.to(self.device)
         prox = self._prox()
         oargs = self._refine_optim_args(self.args)
-        fused = self.args.optimizer == "AdamW" and getattr(self.args, "max_grad_norm", 0) <= 0 and \
-            not getattr(self.args, "distributed", False) and not getattr(self.args, "mm_distributed", False)
+        fused = self.args.optimizer == "AdamW" and not getattr(self.args, "distributed", False) and \
+            not getattr(self.args, "mm_distributed", False) and not getattr(self.args, "force_unfused", False)
         if not fused:
             return self._update_unfused(mm, oargs, prox)
         dev = model.flat.device
+        # fedavgclient.py:98-99: clip_grad_norm_ sits between backward and optimizer.step, so the step is composed from the ABI's pieces
+        # (fc_forward / criterion / fc_backward / fc_prox_term / fc_clip_grad_norm / fc_adamw_step) instead of the one fused call
+        max_norm = float(getattr(self.args, "max_grad_norm", 0) or 0)
         # the first epoch's loader is started NOW: its first batch is assembled (and any sampler RNG is drawn -- nothing below draws from
         # the CPU generator) while the optimizer state is allocated; fedavgclient.py:79 creates the iterator at the loop head
         started = None
@@ -123,6 +126,7 @@ class FedavgClient(BaseClient):
         L = _lib.lib()
         if prox is not None:
             prox_scratch = torch.empty(L.fc_prox_scratch_bytes(model._handle.h), dtype=torch.uint8, device=dev)
+        clip_scratch = torch.empty(L.fc_clip_scratch_bytes(model._handle.h), dtype=torch.uint8, device=dev) if max_norm > 0 else None
         step = 0
         # optimizer state of this round, shared with subclasses' extra steps (CreamFL's public-set distillation)
         st = dict(grads=grads, exp_avg=exp_avg, exp_avg_sq=exp_avg_sq, lr=lr, betas=betas, eps=eps, wd=wd, dev=dev, steps_done=0)
@@ -172,13 +176,22 @@ class FedavgClient(BaseClient):
                 if not self._fused_step_ok(st):
                     self._segmented_step(st, img, ids, labels, B, n_txt, dp, ws, lossbuf)
                     model._wc_version = model.flat._version
-                    if mm.metric_funcs:
-                        i = 0 if self.modality == "img" else 1
-                        logits = torch.empty(B, model.num_classes[i], device=dev)
-                        check(L.fc_copy_outputs(model._handle.h, ptr(ws), ws.numel(), ptr(logits) if i == 0 else None,
-                                                ptr(logits) if i == 1 else None, _lib.stream_ptr()))
-                        for module in mm.metric_funcs.values():
-                            module.collect(logits, labels)
+                    self._collect_metrics(mm, ws, B, labels)
+                    num += 1
+                    continue
+                if max_norm > 0:
+                    self._forward_backward(st, img, ids, labels, B, n_txt, dp, ws, lossbuf)
+                    if prox is not None:
+                        check(L.fc_prox_term(model._handle.h, ptr(model.flat), ptr(prox[0]), float(prox[1]), B, ptr(grads), ptr(lossbuf),
+                                             ptr(prox_scratch), prox_scratch.numel(), _lib.stream_ptr()))
+                    check(L.fc_clip_grad_norm(model._handle.h, ptr(grads), max_norm, ptr(clip_scratch), clip_scratch.numel(), None,
+                                              _lib.stream_ptr()))
+                    check(L.fc_adamw_step(model._handle.h, ptr(model.flat), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), lr, float(betas[0]),
+                                          float(betas[1]), eps, wd, step, _lib.stream_ptr()))
+                    model._bump()                                      # the compute weights are rebuilt by the next prepare_weights()
+                    st["steps_done"] = step
+                    self._count_step(st, None)
+                    self._collect_metrics(mm, ws, B, labels)
                     num += 1
                     continue
                 step_args = (model._handle.h, ptr(model.flat), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(model._wc_or_flat()),
@@ -191,13 +204,7 @@ class FedavgClient(BaseClient):
                 model._wc_version = model.flat._version          # fc_client_step refreshed the compute weights itself
                 st["steps_done"] = step
                 self._count_step(st, None)
-                if mm.metric_funcs:                                    # acc1 etc. for uni-modal clients
-                    i = 0 if self.modality == "img" else 1
-                    logits = torch.empty(B, model.num_classes[i], device=dev)
-                    check(L.fc_copy_outputs(model._handle.h, ptr(ws), ws.numel(), ptr(logits) if i == 0 else None,
-                                            ptr(logits) if i == 1 else None, _lib.stream_ptr()))
-                    for module in mm.metric_funcs.values():
-                        module.collect(logits, labels)
+                self._collect_metrics(mm, ws, B, labels)
                 num += 1
             if not broke:
                 mm.add_loss_sum(lossbuf[0].clone())                    # sum_b loss_b*|b| accumulated on the device
@@ -208,9 +215,53 @@ class FedavgClient(BaseClient):
         # the reference moves the model back to the CPU here (fedavgclient.py:114); weights stay resident in HBM instead
         return mm.results
 
+    def _collect_metrics(self, mm, ws, B, labels):
+        """acc1 etc. for uni-modal clients: the logits of the step's forward are copied out of the workspace."""
+        if not mm.metric_funcs:
+            return
+        model = self.model
+        i = 0 if self.modality == "img" else 1
+        logits = torch.empty(B, model.num_classes[i], device=model.flat.device)
+        check(_lib.lib().fc_copy_outputs(model._handle.h, ptr(ws), ws.numel(), ptr(logits) if i == 0 else None,
+                                         ptr(logits) if i == 1 else None, _lib.stream_ptr()))
+        for module in mm.metric_funcs.values():
+            module.collect(logits, labels)
+
+    def _forward_backward(self, st, img, ids, labels, B, n_txt, dp, ws, lossbuf):
+        """optimizer.zero_grad(); forward; criterion; loss.backward() (fedavgclient.py:79-97) from the ABI's separate entry points:
+        the gradients are left in st['grads'] for whatever has to happen before the optimizer step."""
+        model, L = self.model, _lib.lib()
+        dev = st["dev"]
+        st["grads"].zero_()
+        i = 0 if self.modality == "img" else 1
+        if self.modality == "img+txt":
+            D = model.embed_dim
+            oi, ot = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
+            check(L.fc_forward(model._handle.h, ptr(model.flat), ptr(model._wc_or_flat()), ptr(img), ptr(ids), B, n_txt, 1, ptr(dp), ptr(ws),
+                               ws.numel(), ptr(oi), ptr(ot), _lib.stream_ptr()))
+            da, db = torch.empty_like(oi), torch.empty_like(ot)
+            scratch = torch.empty(L.fc_contrastive_scratch_floats(B), device=dev)
+            from ..criterions import contrastive_tau
+            check(L.fc_contrastive_loss_fwd_bwd(ptr(oi), ptr(ot), B, D, contrastive_tau(), ptr(scratch), scratch.numel(), ptr(lossbuf), ptr(da),
+                                                ptr(db), _lib.stream_ptr()))
+            d0, d1 = da, db
+        else:
+            C_ = model.num_classes[i]
+            lg = torch.empty(B, C_, device=dev)
+            check(L.fc_forward(model._handle.h, ptr(model.flat), ptr(model._wc_or_flat()), ptr(img), ptr(ids), B, n_txt, 0, ptr(dp), ptr(ws),
+                               ws.numel(), ptr(lg) if i == 0 else None, ptr(lg) if i == 1 else None, _lib.stream_ptr()))
+            dl = torch.empty_like(lg)
+            check(L.fc_ce_loss_fwd_bwd(ptr(lg), ptr(labels), B, C_, ptr(lossbuf), ptr(dl), _lib.stream_ptr()))
+            d0, d1 = (dl, None) if i == 0 else (None, dl)
+        check(L.fc_backward(model._handle.h, ptr(model.flat), ptr(model._wc_or_flat()), ptr(d0), ptr(d1), ptr(st["grads"]), ptr(ws), ws.numel(),
+                            _lib.stream_ptr()))
+
     def _device_ring(self):
-        """The fixed device buffers the prefetcher copies this client's batches into (three per position): the same addresses step after
-        step and round after round, which is what lets fc_client_step replay its captured graphs."""
+        """Fixed device buffers for the prefetcher (three per position: the same addresses step after step), which is what lets a
+        step_graph model replay its captured graphs.  Only then: otherwise the prefetcher allocates per batch from torch's caching
+        allocator and a client holds no HBM between rounds."""
+        if not getattr(self.model, "_options", {}).get("step_graph"):
+            return None
         ring = getattr(self, "_dev_ring", None)
         if ring is None:
             ring = self._dev_ring = {}

@@ -37,8 +37,15 @@ class Comm:
     def from_torch_dist(cls) -> "Comm":
         import torch.distributed as dist
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as e:       # the other ranks are waiting in the broadcast: tell them instead of leaving them there
+                box[0] = ("error", f"{type(e).__name__}: {e}")
         dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], tuple):
+            raise RuntimeError(f"rank 0 could not create an RCCL id: {box[0][1]}")
         return cls.create(box[0], rank, world)
 
     @classmethod

@@ -154,9 +154,10 @@ class FedavgServer(BaseServer):
                 client.model.set_trainable(name, False)
 
     def _unfreeze_params(self, client):
+        """fedavgserver.py:426-429: requires_grad = True on EVERY parameter -- including ``aux_weight`` of a model built with
+        ``aux_trained=False``: past the freeze window the freeze-modality clients train their aux weights (a quirk of the reference that
+        its results contain, so it is kept)."""
         for name in client.model.segments:
-            if "aux_weight" in name and not self.args.aux_trained:
-                continue
             client.model.set_trainable(name, True)
 
     def _request(self, ids, eval=False, participated=True, retain_model=True, save_raw=False):

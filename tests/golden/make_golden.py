@@ -8,6 +8,8 @@ Outputs (tests/golden/):
     model_<case>.json   forward outputs, loss, gradient / post-AdamW fingerprints (full tensors for the toy case)
     update_toy.json     FedavgClient.update() result dict + final weights fingerprint
     update_prox_toy.json  the same for FedproxClient.update() (mu = 0.5)
+    update_clip_toy.json  the same for FedavgClient.update() with max_grad_norm = 1.0
+    server_update.json    three rounds of FedavgServer.update(): warm-up filter, freeze / unfreeze, aux refresh, LR decay
     agg.json            FedavgServer._aggregate outputs over the scope / compensation matrix
     agg_colearn.json    the same with colearn_param='attn' img+txt models (shared Attention tensors listed under both towers' keys)
     sampling.json       FedavgServer._sample_clients id lists
@@ -171,6 +173,95 @@ def update_prox_case():
     with open(os.path.join(HERE, "update_prox_toy.json"), "w") as f:
         json.dump(rec, f)
     print("update prox", res)
+
+
+def update_clip_case():
+    """FedavgClient.update() with max_grad_norm = 1.0 (fedavgclient.py:98-99: clip_grad_norm_ between backward and the optimizer)."""
+    c = CASES["toy"]
+    args = RefArgs(E=2, B=4, lr=1e-3, optimizer="AdamW", no_shuffle=True, max_grad_norm=1.0)
+    ds = SynthPairs(10, 8, 30)
+    cl = ref.fedavgclient.FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt",
+                                       eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cpu"
+    m = build(c["mk"])
+    cl.download({"Flickr30k": m})
+    # the clip must bite for the fixture to mean anything: record the first batch's total gradient norm
+    mm = build(c["mk"])
+    mm.train()
+    img, ids = torch.stack([ds[i][0] for i in range(4)]), torch.stack([ds[i][1] for i in range(4)])
+    torch.nn.ContrastiveLoss()(*mm([img, ids], feat_out=True)).backward()
+    norm0 = float(torch.nn.utils.clip_grad_norm_(mm.parameters(), 1.0))
+    assert norm0 > 1.5, norm0
+    res = cl.update()
+    sd = cl.upload()
+    rec = dict(results={str(k): v for k, v in res.items()}, n=10, B=4, E=2, lr=1e-3, max_grad_norm=1.0, first_batch_grad_norm=norm0,
+               after={k: pack(v, True) for k, v in sd.items() if v.dtype.is_floating_point})
+    with open(os.path.join(HERE, "update_clip_toy.json"), "w") as f:
+        json.dump(rec, f)
+    print("update clip", res, "first-batch grad norm", norm0)
+
+
+def server_update_case():
+    """The REAL FedavgServer.update() (fedavgserver.py:784-856) for three rounds on toy models with real FedavgClients: sampling with the
+    warm-up filter (:307-308), the request fan-out with freeze / unfreeze (:505-520, 417-429), per-dataset _aggregate, the aux refresh
+    (:821-845), LR decay (:851-852).  Recorded per round: sampled ids, the lr every trained client saw, requires_grad of every client
+    parameter at the time of its update(), the clients' result dicts, curr_lr afterwards and every global model's full state_dict."""
+    from unittest import mock
+    from collections import defaultdict
+    import fl_util as F
+    args = RefArgs(**F.ROUND_ARGS)
+    srv = object.__new__(ref.fedavgserver.FedavgServer)
+    srv.args = args
+    srv._round = 0
+    srv.writer = mock.MagicMock()
+    srv.results = defaultdict(dict)
+    srv.curr_lr = args.lr
+    srv.Cs = dict(F.ROUND_CS)
+    srv.global_models = {}
+    for i, ds in enumerate(F.ROUND_DS):
+        m = ref.mome.ModalityAgnosticTransformer(with_aux=True, aux_trained=False, **F.round_model_kwargs(ds))
+        m.sync_shared_weights()
+        m.load_state_dict(det_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, base_seed=31 * (i + 1)))
+        srv.global_models[ds] = m
+    srv._init_param_scope(args.shared_param, args.share_scope)
+    clients = []
+    for cid, ds, n in F.ROUND_LAYOUT:
+        task, mod = F.ROUND_DS[ds]
+        d = F.round_dataset(cid, ds, n)
+        cl = ref.fedavgclient.FedavgClient(args=args, training_set=d, test_set=d, task=task, modality=mod,
+                                           eval_metrics=["acc1"] if task == "cls" else [], criterion="CrossEntropyLoss" if task == "cls" else "ContrastiveLoss")
+        cl.id, cl.dataset, cl.device = cid, ds, "cpu"
+        clients.append(cl)
+    srv._clients = clients
+    trace = {}
+    for cl in clients:
+        def spy(cl=cl, orig=cl.update):
+            trace[cl.id] = dict(lr=float(cl.args.lr), requires_grad={k: bool(p.requires_grad) for k, p in cl.model.named_parameters()})
+            res = orig()
+            trace[cl.id]["result"] = {str(k): v for k, v in res.items()}
+            return res
+        cl.update = spy
+    random.seed(F.ROUND_SEED)
+    rec = dict(scope=dict(srv.param_scope), rounds=[],
+               init={ds: {k: pack(v, True) for k, v in m.state_dict().items() if v.dtype.is_floating_point} for ds, m in srv.global_models.items()})
+    for r in range(1, F.ROUND_N + 1):
+        srv._round = r
+        trace.clear()
+        ids = srv.update()
+        assert all(c.model is None for c in clients)
+        rec["rounds"].append(dict(round=r, ids=[int(i) for i in ids], curr_lr=float(srv.curr_lr),
+                                  clients={str(k): v for k, v in trace.items()},
+                                  models={ds: {k: pack(v, True) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+                                          for ds, m in srv.global_models.items()}))
+        print("server round", r, ids, srv.curr_lr, {k: sum(v["requires_grad"].values()) for k, v in trace.items()})
+    # the three behaviours the fixture exists for must actually occur in it
+    r1, r2, r3 = rec["rounds"]
+    assert all(F.ROUND_DS[F.ROUND_LAYOUT[i][1]][1] == "txt" for i in r1["ids"])                                   # warm-up filter
+    assert any(not v for c in r2["clients"].values() for k, v in c["requires_grad"].items() if "aux_weight" not in k)   # freeze
+    assert any(v for i, c in r3["clients"].items() if F.ROUND_LAYOUT[int(i)][1] == "CIFAR100" for k, v in c["requires_grad"].items() if "aux_weight" in k)  # unfreeze quirk
+    with open(os.path.join(HERE, "server_update.json"), "w") as f:
+        json.dump(rec, f)
+    print("server update ok")
 
 
 # ----------------------------------------------------------------------------------------- aggregation
@@ -455,6 +546,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "agg_colearn":
         agg_case("attn")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "server_update":
+        server_update_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "clip":
+        update_clip_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "prox":
         update_prox_case()
         sys.exit(0)
@@ -462,6 +559,8 @@ if __name__ == "__main__":
         model_case(n, c)
     update_case()
     update_prox_case()
+    update_clip_case()
+    server_update_case()
     agg_case()
     agg_case("attn")
     sampling_case()

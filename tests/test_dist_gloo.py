@@ -108,14 +108,16 @@ def _many_worker(rank, world, port, idx, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("idx", [1, 4])
-def test_three_global_models_share_one_all_reduce(idx):
+@pytest.mark.parametrize("idx,world", [(1, 2), (4, 2), (0, 4), (2, 4)])
+def test_three_global_models_share_one_all_reduce(idx, world):
     """fedavgserver.py:812-819 aggregates one global model per dataset; across ranks the three partials travel in ONE all-reduce
-    (aggregate_many) and every rank ends with the reference's models (golden agg.json)."""
+    (aggregate_many) and every rank ends with the reference's models (golden agg.json).  world = 4 with five or six sampled clients:
+    ranks 0 and 1 queue two clients each (positions p % 4, fedavgserver.py:310-311) and pre-accumulate them in their partial, ranks 2 / 3
+    own one or none -- the shape of the driver's `--gpus 4/8 --clients-per-rank 2` runs."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_many_worker, args=(r, 2, port, idx, q)) for r in range(2)]
+    procs = [ctx.Process(target=_many_worker, args=(r, world, port, idx, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

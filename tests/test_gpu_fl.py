@@ -14,28 +14,7 @@ from synth import det_ids, det_tensor
 pytestmark = pytest.mark.gpu
 
 
-class SynthPairs(torch.utils.data.Dataset):
-    def __init__(self, n, seq, vocab):
-        self.img = det_tensor((n, 3, 224, 224), 2000, 0.5)
-        self.ids = det_ids((n, seq), 11, vocab)
-
-    def __len__(self):
-        return self.img.shape[0]
-
-    def __getitem__(self, i):
-        return self.img[i], self.ids[i], i // 5, i, i
-
-
-class SynthCls(torch.utils.data.Dataset):
-    def __init__(self, n, kind, classes, seq=8, vocab=30, seed=0):
-        self.x = det_tensor((n, 3, 224, 224), 3000 + seed, 0.5) if kind == "img" else det_ids((n, seq), 13 + seed, vocab)
-        self.y = (torch.arange(n) * 7 + seed) % classes
-
-    def __len__(self):
-        return self.x.shape[0]
-
-    def __getitem__(self, i):
-        return self.x[i], self.y[i]
+from fl_util import SynthCls, SynthPairs  # noqa: E402  (shared with the golden generator)
 
 
 def toy_model(precision="fp32"):
@@ -46,11 +25,16 @@ def toy_model(precision="fp32"):
     return m.cuda()
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_client_update_matches_reference_result_dict(fused):
+# the three forms of the batch-loop body: one fused fc_client_step | composed from the ABI's pieces with fc_clip_grad_norm in between
+# (max_grad_norm > 0; 1e9 never bites) | torch.optim + autograd over the HIP forward / backward (any other optimizer)
+PATHS = {"fused": dict(max_grad_norm=0.0), "composed": dict(max_grad_norm=1e9), "torch": dict(max_grad_norm=0.0, force_unfused=True)}
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+def test_client_update_matches_reference_result_dict(path):
     from fedcola_amd.client.fedavgclient import FedavgClient
     rec = G.load("update_toy.json")
-    args = RefArgs(E=rec["E"], B=rec["B"], lr=rec["lr"], optimizer="AdamW", no_shuffle=True, max_grad_norm=0.0 if fused else 1e9)
+    args = RefArgs(E=rec["E"], B=rec["B"], lr=rec["lr"], optimizer="AdamW", no_shuffle=True, **PATHS[path])
     ds = SynthPairs(rec["n"], 8, 30)
     cl = FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
     cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cuda"
@@ -71,6 +55,146 @@ def test_client_update_matches_reference_result_dict(fused):
             D = exp.numel() // 3
             err[D:2 * D] = 0
         assert err.max() <= 2.5e-3, k
+
+
+
+def _after_err(sd, after):
+    worst = {}
+    for k, r in after.items():
+        exp = torch.tensor(r["full"]).reshape(r["shape"])
+        err = (sd[k].detach().cpu() - exp).abs()
+        if k.endswith("attn.qkv.bias"):          # the key bias: exactly-zero true gradient, Adam steps on round-off (see above)
+            D = exp.numel() // 3
+            err[D:2 * D] = 0
+        worst[k] = float(err.max())
+    return worst
+
+
+@pytest.mark.parametrize("path", ["composed", "torch"])
+def test_client_update_with_gradient_clipping_matches_the_reference(path):
+    """fedavgclient.py:98-99: clip_grad_norm_(parameters, max_grad_norm) between backward and the optimizer.  The golden comes from the
+    reference's update() with max_grad_norm = 1.0 on a batch whose gradient norm is 16: the clip bites at every step.  The composed path
+    (fc_forward / criterion / fc_backward / fc_clip_grad_norm / fc_adamw_step) is the default for such clients."""
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    rec = G.load("update_clip_toy.json")
+    assert rec["first_batch_grad_norm"] > 2 * rec["max_grad_norm"]
+    args = RefArgs(E=rec["E"], B=rec["B"], lr=rec["lr"], optimizer="AdamW", no_shuffle=True, max_grad_norm=rec["max_grad_norm"],
+                   force_unfused=(path == "torch"))
+    ds = SynthPairs(rec["n"], 8, 30)
+    cl = FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cuda"
+    cl.download({"Flickr30k": toy_model()})
+    if path == "composed":                       # the clipped round must not leave the device path
+        cl._update_unfused = None
+    res = cl.update()
+    plain = G.load("update_toy.json")
+    for e in (1, 2):
+        assert abs(res[e]["loss"] - rec["results"][str(e)]["loss"]) <= 3e-4, (e, res[e], rec["results"][str(e)])
+    worst = _after_err(cl.upload(), rec["after"])
+    assert max(worst.values()) <= 2.5e-3, max(worst.items(), key=lambda kv: kv[1])
+    # Adam is invariant to a UNIFORM gradient scale, but the clip factor changes from step to step, so the moments mix differently scaled
+    # gradients: the second epoch's loss of the clipped run is 1.2e-2 away from the unclipped golden -- 40x the tolerance above
+    assert abs(res[2]["loss"] - plain["results"]["2"]["loss"]) > 5e-3
+
+
+def _round_server(device="cuda"):
+    """A FedavgServer shell set up like tests/golden/make_golden.py::server_update_case builds the reference's."""
+    import random
+    from collections import defaultdict
+    import fl_util as F
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    from fedcola_amd.server.fedavgserver import FedavgServer
+    from synth import det_state_dict
+    args = RefArgs(**F.ROUND_ARGS)
+    srv = object.__new__(FedavgServer)
+    srv.args = args
+    srv._round = 0
+    srv.writer = None
+    srv.results = defaultdict(dict)
+    srv.curr_lr = args.lr
+    srv.Cs = dict(F.ROUND_CS)
+    srv.global_models = {}
+    for i, ds in enumerate(F.ROUND_DS):
+        m = M(with_aux=True, aux_trained=False, init=False, precision="fp32", **F.round_model_kwargs(ds))
+        m.load_state_dict(det_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, base_seed=31 * (i + 1)))
+        srv.global_models[ds] = m.to(device)
+    srv._init_param_scope(args.shared_param, args.share_scope)
+    clients = []
+    for cid, ds, n in F.ROUND_LAYOUT:
+        task, mod = F.ROUND_DS[ds]
+        d = F.round_dataset(cid, ds, n)
+        cl = FedavgClient(args=args, training_set=d, test_set=d, task=task, modality=mod, eval_metrics=["acc1"] if task == "cls" else [],
+                          criterion="CrossEntropyLoss" if task == "cls" else "ContrastiveLoss")
+        cl.id, cl.dataset, cl.device = cid, ds, device
+        clients.append(cl)
+    srv._clients = clients
+    random.seed(F.ROUND_SEED)
+    return srv, F
+
+
+def test_three_server_rounds_match_the_reference_update():
+    """A16: FedavgServer.update() as a whole against tests/golden/server_update.json = the REAL reference update() run for three rounds
+    (fedavgserver.py:784-856): round 1 is a txt-only warm-up round (:307-308), in round 2 the img clients' scope-'all' parameters are
+    frozen (:417-420, 511-514), in round 3 every parameter of the img clients is unfrozen -- including aux_weight of an aux_trained=False
+    model (:426-429) -- and after every round the aux weights are refreshed from the other modality's aggregated model (:821-845) and the
+    learning rate decays (:851-852).  Asserted per round: sampled ids, the lr each client trained with, requires_grad of every client
+    parameter at its update(), the clients' result dicts, curr_lr, every tensor of every global model."""
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    rec = G.load("server_update.json")
+    FedavgClient._POOL.clear()
+    srv, F = _round_server()
+    assert dict(srv.param_scope) == rec["scope"]
+    for ds, m in srv.global_models.items():
+        assert max(_after_err(m.state_dict(), rec["init"][ds]).values()) == 0.0
+    trace = {}
+    for cl in srv.clients:
+        def spy(cl=cl, orig=cl.update):
+            trace[cl.id] = dict(lr=float(cl.args.lr), requires_grad={k: bool(p.requires_grad) for k, p in cl.model.named_parameters()})
+            res = orig()
+            trace[cl.id]["result"] = res
+            return res
+        cl.update = spy
+    report = []
+    for r, exp in enumerate(rec["rounds"], start=1):
+        srv.round = r
+        trace.clear()
+        ids = srv.update()
+        assert ids == exp["ids"], (r, ids, exp["ids"])
+        assert srv.curr_lr == pytest.approx(exp["curr_lr"], rel=1e-12)
+        assert all(c.model is None for c in srv.clients)
+        assert set(trace) == {int(k) for k in exp["clients"]}
+        for cid, e in exp["clients"].items():
+            t = trace[int(cid)]
+            assert t["lr"] == pytest.approx(e["lr"], rel=1e-12)
+            assert t["requires_grad"] == e["requires_grad"], (r, cid, [k for k in e["requires_grad"] if e["requires_grad"][k] != t["requires_grad"].get(k)])
+            for ep, v in e["result"].items():
+                got = t["result"][int(ep)]
+                assert abs(got["loss"] - v["loss"]) <= 1e-3 * max(1.0, abs(v["loss"])), (r, cid, got, v)
+                assert set(got["metrics"]) == set(v["metrics"])
+                for name, val in v["metrics"].items():
+                    assert abs(got["metrics"][name] - val) <= 1e-6, (r, cid, name)
+        for ds, m in srv.global_models.items():
+            sd = m.state_dict()
+            worst = _after_err(sd, exp["models"][ds])
+            k, w = max(worst.items(), key=lambda kv: kv[1])
+            report.append((r, ds, k, w))
+            assert w <= 2.5e-3, (r, ds, k, w)          # Adam's +-lr steps on near-zero gradients (see the client test above)
+            aux = {k: w for k, w in worst.items() if "aux_weight" in k}
+            assert len(aux) == (0 if ds == "Flickr30k" else 4)
+        # the aux refresh is a copy of the other modality's aggregated weights: exact within this run
+        gi, gt = srv.global_models["CIFAR100"].state_dict(), srv.global_models["AG_NEWS"].state_dict()
+        for k in srv.global_models["CIFAR100"].aux_params():
+            assert torch.equal(gi[k], gt[k.replace("aux_", "").replace("blockses.0", "blockses.1")]), k
+        for k in srv.global_models["AG_NEWS"].aux_params():
+            assert torch.equal(gt[k], gi[k.replace("aux_", "").replace("blockses.1", "blockses.0")]), k
+    print("worst per round / model:", report)
+    # the fixture's three behaviours are in it
+    assert all(F.ROUND_DS[F.ROUND_LAYOUT[i][1]][1] == "txt" for i in rec["rounds"][0]["ids"])
+    r2 = rec["rounds"][1]["clients"]["0"]["requires_grad"]
+    assert not r2["blockses.0.0.attn.qkv.weight"] and r2["blockses.0.0.mlp.fc1.weight"]
+    assert rec["rounds"][2]["clients"]["0"]["requires_grad"]["blockses.0.0.attn.qkv.aux_weight"]
+    FedavgClient._POOL.clear()
 
 
 def test_recycled_client_model_is_the_deep_copy_the_reference_makes():
@@ -304,13 +428,13 @@ def test_central_evaluate_retrieval_and_classification():
     assert res["metrics"]["acc1"] == pytest.approx(hit / len(ds), abs=1e-12)
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_fedprox_update_matches_reference_result_dict(fused):
-    """N3: FedproxClient.update (fused fc_client_step_prox / unfused torch path) against the reference's FedproxClient.update golden."""
+@pytest.mark.parametrize("path", list(PATHS))
+def test_fedprox_update_matches_reference_result_dict(path):
+    """N3: FedproxClient.update (fused fc_client_step_prox / composed with fc_prox_term / torch path) against the reference's
+    FedproxClient.update golden."""
     from fedcola_amd.client.fedproxclient import FedproxClient
     rec = G.load("update_prox_toy.json")
-    args = RefArgs(E=rec["E"], B=rec["B"], lr=rec["lr"], optimizer="AdamW", no_shuffle=True, max_grad_norm=0.0 if fused else 1e9, mu=rec["mu"],
-                   algorithm="fedprox")
+    args = RefArgs(E=rec["E"], B=rec["B"], lr=rec["lr"], optimizer="AdamW", no_shuffle=True, mu=rec["mu"], algorithm="fedprox", **PATHS[path])
     ds = SynthPairs(rec["n"], 8, 30)
     cl = FedproxClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
     cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cuda"

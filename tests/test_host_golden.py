@@ -389,3 +389,50 @@ def test_refresh_from_equals_deepcopy_on_the_host():
     before = other.flat.detach().clone()
     assert other.refresh_from(src) is False and torch.equal(other.flat, before)
     assert src.refresh_from(src) is False
+
+
+def test_server_update_bookkeeping_matches_the_reference_rounds():
+    """The host half of FedavgServer.update() against tests/golden/server_update.json (the REAL reference update(), three rounds): sampled
+    ids incl. the warm-up filter (fedavgserver.py:307-308), the lr handed to each client (:509), requires_grad of every client parameter
+    under freeze / unfreeze (:417-429, 511-516 -- the unfreeze includes aux_weight of an aux_trained=False model), LR decay (:851-852).
+    Client training and the device blend are stubbed out here (no GPU); tests/test_gpu_fl.py runs the same rounds for real."""
+    import random
+    from collections import defaultdict
+    import fl_util as F
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    from fedcola_amd.server.fedavgserver import FedavgServer
+    from refstub import RefArgs
+    rec = G.load("server_update.json")
+    args = RefArgs(**F.ROUND_ARGS)
+    srv = object.__new__(FedavgServer)
+    srv.args, srv._round, srv.writer, srv.results, srv.curr_lr, srv.Cs = args, 0, None, defaultdict(dict), args.lr, dict(F.ROUND_CS)
+    srv.global_models = {ds: M(with_aux=True, aux_trained=False, init=False, **F.round_model_kwargs(ds)) for ds in F.ROUND_DS}
+    srv._init_param_scope(args.shared_param, args.share_scope)
+    assert dict(srv.param_scope) == rec["scope"]
+    trace = {}
+    clients = []
+    for cid, ds, n in F.ROUND_LAYOUT:
+        task, mod = F.ROUND_DS[ds]
+        cl = object.__new__(FedavgClient)
+        cl._BaseClient__identifier, cl._BaseClient__model = cid, None
+        cl.args, cl.dataset, cl.task, cl.modality, cl.training_set = args, ds, task, mod, list(range(n))
+
+        def fake_update(cl=cl):
+            trace[cl.id] = dict(lr=float(cl.args.lr), requires_grad={k: bool(p.requires_grad) for k, p in cl.model.named_parameters()})
+            return {1: {"loss": 0.0, "metrics": {}}}
+        cl.update = fake_update
+        clients.append(cl)
+    srv._clients = clients
+    srv._aggregate = lambda *a, **k: None
+    random.seed(F.ROUND_SEED)
+    for r, exp in enumerate(rec["rounds"], start=1):
+        srv.round = r
+        trace.clear()
+        assert srv.update() == exp["ids"]
+        assert srv.curr_lr == pytest.approx(exp["curr_lr"], rel=1e-12)
+        assert set(trace) == {int(k) for k in exp["clients"]}
+        for cid, e in exp["clients"].items():
+            assert trace[int(cid)]["lr"] == pytest.approx(e["lr"], rel=1e-12)
+            assert trace[int(cid)]["requires_grad"] == e["requires_grad"], (r, cid)
+        assert all(c.model is None for c in clients)
