@@ -210,5 +210,11 @@ def test_vit_b_width_step_vs_oracle(kind, prec, otol, gtol):
         assert len(mass_of) >= 0.7 * len(rows), "the mass recorder lost track of the block gradients"
         for k, kappa, mine, theirs in rows:
             assert mine <= ETA_BOUND * kappa, f"{k}: {mine:.2e} of its maximum from the exact gradient at condition number {kappa:.1f} (bound {ETA_BOUND * kappa:.2e})"
+        # ... AND north_star's plain bound, without the conditioning: every tensor within 1e-4 of the exact gradient relative to its
+        # maximum (the kappa form alone would let a 10x regression of a cancelling tensor through).  The worst tensor
+        # (blockses.1.1.norm1.bias, kappa 9.3) measures 9.62e-5: a thin margin, but the fp32 mode has no atomics on these tensors and a fixed
+        # reduction order -- the figure is the same on every run and every box until a kernel changes, and then this line is the alarm.
+        for k, kappa, mine, theirs in rows:
+            assert mine <= 1e-4, f"{k}: {mine:.2e} of its maximum from the exact gradient (plain bound 1e-4; condition number {kappa:.1f})"
     else:
         assert worst1d[1] <= gtol, f"worst 1-D gradient tensor {worst1d}"
