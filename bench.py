@@ -444,7 +444,103 @@ def extra_legs(a, args, model, step, B, seq, dev, dev_step_s, make_ws=None):
                                aggregate_ms=round(d_ag * 1e3, 2),
                                note="FedavgClient.download() + update() (E = 1, 20 x B pairs from host memory through the client's default loader and "
                                     "DevicePrefetcher, per-epoch loss read) + aggregation of the client into the global model; best of 2 rounds after a warm-up round")
+    del client, ds
+    # ---- client_round at the reference's own run settings (/root/reference/scripts/flickr.sh:13: --B 112 --E 5) and a uni-modal `--with_aux --aux_trained` client
+    try:
+        out["client_round_b112_e5"] = _round_leg(args, copy.deepcopy(model), seq, dev, B=112, E=5, steps_per_epoch=8, kind="img+txt",
+                                                 note="scripts/flickr.sh: --B 112 --E 5; 8 batches per epoch from host memory, one download / update / aggregate round")
+    except Exception as e:      # a leg must never cost the line
+        out["client_round_b112_e5"] = dict(error=f"{type(e).__name__}: {e}"[:200])
+    try:
+        out["client_round_img_aux"] = _round_leg(args, None, seq, dev, B=B, E=1, steps_per_epoch=20, kind="img",
+                                                 note="uni-modal image classifier client (CIFAR100-shaped labels, 100 classes) of a FedCola run: --with_aux --aux_trained "
+                                                      "(CrossModalReparamLinear, W + s A folded on upload), cross entropy, acc1 collected per step")
+    except Exception as e:
+        out["client_round_img_aux"] = dict(error=f"{type(e).__name__}: {e}"[:200])
     return out
+
+
+class InMemoryCls:
+    """CIFAR100-shaped synthetic classifier data in host memory, resized to the model's 224 x 224 like the reference's --resize 224 chain."""
+
+    def __init__(self, n, classes, seed=0):
+        import torch
+        g = torch.Generator().manual_seed(5000 + seed)
+        self.x = (torch.randn(n, 3, 224, 224, generator=g) * 0.5).clamp_(-1, 1)
+        self.y = torch.randint(0, classes, (n,), generator=g)
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return self.x[i], self.y[i]
+
+    def get_batch(self, idxs, out=None):
+        import torch
+        i = torch.as_tensor(idxs)
+        if out is None:
+            return self.x[i], self.y[i]
+        torch.index_select(self.x, 0, i, out=out[0])
+        torch.index_select(self.y, 0, i, out=out[1])
+        return out
+
+
+def _round_leg(args, gmodel, seq, dev, B, E, steps_per_epoch, kind, note):
+    """One federated round of ONE client through the plugin surface: download() + update() (E epochs) + upload fold / aggregation."""
+    import torch
+    from fedcola_amd import aggregate as agg
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    from fedcola_amd.mome import create_model
+
+    class CArgs:
+        pass
+    ca = CArgs()
+    aux = kind != "img+txt"
+    ca.__dict__.update(dict(vocab_size=args.vocab_size, seq_len=seq, dropout=args.dropout, optimizer="AdamW", lr=1e-4, weight_decay=0.0, E=E, B=B,
+                            no_shuffle=False, debug=False, with_aux=aux, aux_trained=aux, aux_attn_only=False, aux_mlp_only=False, max_grad_norm=0.0,
+                            distributed=False, mm_distributed=False, train_only=True, precision=getattr(args, "precision", "bf16"),
+                            shared_param="none", share_scope="dataset", colearn_param="none"))
+    n = steps_per_epoch * B
+    if kind == "img+txt":
+        ds = InMemoryPairs(n, seq, args.vocab_size, seed=7)
+        client = FedavgClient(ca, ds, ds, task="rtv", eval_metrics=[], modality="img+txt", criterion="ContrastiveLoss")
+        name = "Flickr30k"
+    else:
+        ds = InMemoryCls(n, 100, seed=7)
+        client = FedavgClient(ca, ds, ds, task="cls", eval_metrics=["acc1"], modality="img", criterion="CrossEntropyLoss")
+        name = "CIFAR100"
+        torch.manual_seed(2)
+        gmodel = create_model("mome_small_patch16", False, args=ca, num_classes=[100, None], modalities=["img", None], tasks=["cls", None],
+                              with_aux=True, aux_trained=True).to(dev)
+    client._BaseClient__identifier = 0
+    client.dataset = name
+    seg = gmodel.segments
+    drop = (lambda k: aux and ("aux" in k or "cross_modal_scale" in k))
+    keys = [k for k in gmodel.required_params().keys()]
+    plan = agg.build_plan(gmodel, [0], {k: {0: 1.0} for k in keys}, {0: {k: v for k, v in seg.items() if not drop(k)}})
+    rounds = []
+    res = None
+    for r in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        client.download({name: gmodel})
+        res = client.update()
+        if aux:
+            client.upload()                        # folds W + s A on the device; the aggregation below reads the folded buffer
+            src = client._folded
+        else:
+            src = client.model.flat.data
+        agg.aggregate(gmodel, plan, {0: src}, rank=0, world=1)
+        torch.cuda.synchronize()
+        rounds.append(time.perf_counter() - t0)
+    d = rounds[-1]
+    steps = E * steps_per_epoch
+    leg = dict(value=round(steps * B / d, 1), unit=("img-txt pairs/s" if kind == "img+txt" else "images/s"), ms_per_round=round(d * 1e3, 2),
+               ms_per_step=round(d / steps * 1e3, 3), B=B, E=E, steps_per_round=steps, epoch_loss=round(float(res[E]["loss"]), 4), note=note + "; second round timed")
+    if kind != "img+txt":
+        leg["acc1"] = round(float(res[E]["metrics"]["acc1"]), 4)
+    return leg
 
 
 def free_port():

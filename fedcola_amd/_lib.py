@@ -53,7 +53,6 @@ SIGNATURES = {
     "fc_model_num_segments": (_I, [_P]),
     "fc_model_segment": (C.c_int, [_P, _I, C.POINTER(FcSegment)]),
     "fc_model_set_trainable": (C.c_int, [_P, _I, _I]),
-    "fc_model_set_option": (C.c_int, [_P, _I, _I]),
     "fc_workspace_bytes": (_Z, [_P, _I, _I]),
     "fc_compute_weights_bytes": (_Z, [_P]),
     "fc_prepare_weights": (C.c_int, [_P, _P, _P, _P]),
@@ -102,8 +101,6 @@ SIGNATURES = {
     "fc_k_attention_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fc_k_attention_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fc_k_dw": (C.c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "fc_k_mlp_pack": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
-    "fc_k_mlp_fused": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "fc_k_adamw": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "fc_k_cast": (C.c_int, [_I, _P, _P, _L, _P]),
     "fc_image_u8_to_f32": (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
@@ -111,6 +108,18 @@ SIGNATURES = {
     "fc_retrieval_best_ranks": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, C.c_size_t, _P, _P]),
     "fc_k_sim_f64": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
 }
+
+# the tools build (-DFC_PROBES, FC_PROBES_LIB=1) additionally exports the `#ifdef FC_PROBES` block of the header
+PROBES_SIGNATURES = {
+    "fc_model_set_option": (C.c_int, [_P, _I, _I]),
+    "fc_dbg_step_graph_hits": (C.c_long, [_P]),
+    "fc_k_mlp_pack": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
+    "fc_k_mlp_fused": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+}
+
+
+def is_probes_build() -> bool:
+    return hasattr(lib(), "fc_model_set_option")
 
 
 def lib():
@@ -129,6 +138,11 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in PROBES_SIGNATURES.items():
+            if hasattr(l, name):
+                fn = getattr(l, name)
+                fn.restype = res
+                fn.argtypes = args
         _lib = l
     return _lib
 

@@ -166,7 +166,9 @@ int fc_dw_x3(const float* dY, const float* X, float* dW, float* db, int rows, in
 struct GemmProb { const bf16_t* A; const bf16_t* B; void* C; long lda, ldb, ldc; int M; GemmEpi e; };
 struct GemmGroup { GemmProb p[2]; int N, K, tiles_n, tiles0, ntiles; };
 int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t s);
-void fc_gemm_set_form(int form);      // process-wide: 0 | 64 | 3 | 4 (fc_mfma.hip)
+#ifdef FC_PROBES
+void fc_gemm_set_form(int form);      // process-wide: 0 | 64 | 3 | 4 (fc_mfma.hip; tools build)
+#endif
 
 // ---- fused MLP (fc_mlp.hip): fc1 -> GELU -> fc2 per 64-row panel, or its backward mirror; D = 384 only.  The weights come from streams packed
 // in MFMA-fragment order (fc_mlp_pack: one launch for a table of {W1, W2, forward stream, backward stream} jobs, fc_mlp_pack_elems bf16 each).

@@ -516,6 +516,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_mfma(GemmGroup g) {
 }
 
 
+#ifdef FC_PROBES      // round-5 experiments (64-row ring, split reduction): faster stand-alone, slower in the step (profiles/r05) -- tools build only
 // ======================================================================== 64 x 128 tiles, one per workgroup, deep staging ring
 // The launches this is for: a chain's N = 384 products with a long reduction (fc2 forward, fc1 dX: K = 1 536; qkv dX: K = 1 152) at
 // 4 334 rows -- 102 tiles of 128 x 128, one workgroup alone on each of 102 CUs walking 18-24 k-steps, each k-step waiting out a whole
@@ -608,7 +609,6 @@ __global__ void __launch_bounds__(256, 1) k_gemm_d64(GemmGroup g) {
 // Measured (profiles/r05/gemm_splitk_cold.txt, gemm_splitk_in_step_ab.txt): 24.5 -> 19.2 us (fc2 forward) and 20-24 -> 15.3 us (fc1 / qkv dX) at chain
 // size, 24.3 -> 18.6 / 14.4 at the text tower's 2 048 rows, 30.6 -> 42.4 at the full batch -- and the B = 64 step 4.55 -> 4.70 ms (+3 %): 204
 // workgroups x 15-19 us is MORE workgroup-time than 102 x 24.5, and the step pays for workgroup-time, not for one kernel's latency.
-#ifdef FC_PROBES
 template <int BMODE, typename TC, int EPI>
 __global__ void __launch_bounds__(256, 2) k_gemm_sk(GemmGroup g, float* __restrict__ part, unsigned* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x (A 16 KB | B 16 KB); the epilogue image aliases buffer 0
@@ -867,15 +867,19 @@ static int launch_gemm(const GemmGroup& g, int k, hipStream_t s, bool mt64 = fal
 #define GO(E) return launch_gemm_epi<AM, BMo, TC, E>(g, s)
 #define GO64(E) return launch_gemm_epi<AM, BMo, TC, E, 64>(g, s)
   if (AM == KC && BMo == KC && sizeof(TC) == 2) {   // forward linears
+#ifdef FC_PROBES
     if constexpr (AM == KC && BMo == KC && sizeof(TC) == 2) {
       if (mt64) switch (k) { case EPI_BIAS: GO64(EPI_BIAS); case EPI_RES: GO64(EPI_RES); case EPI_RES_SCALE: GO64(EPI_RES_SCALE); }
     }
+#endif
     switch (k) { case EPI_BIAS: GO(EPI_BIAS); case EPI_RES: GO(EPI_RES); case EPI_RES_SCALE: GO(EPI_RES_SCALE); case EPI_GELU: GO(EPI_GELU);
                  case EPI_PATCH: GO(EPI_PATCH); case EPI_PLAIN: GO(EPI_PLAIN); case EPI_GELU_SG: GO(EPI_GELU_SG); }
   } else if (AM == KC && BMo == KR && sizeof(TC) == 2) {   // dX
+#ifdef FC_PROBES
     if constexpr (AM == KC && BMo == KR && sizeof(TC) == 2) {
       if (mt64 && k == EPI_PLAIN) GO64(EPI_PLAIN);
     }
+#endif
     switch (k) { case EPI_PLAIN: GO(EPI_PLAIN); case EPI_GELU_GRAD: GO(EPI_GELU_GRAD); case EPI_BIAS: GO(EPI_BIAS); case EPI_MUL: GO(EPI_MUL); }
   } else {
     switch (k) { case EPI_PLAIN: GO(EPI_PLAIN); case EPI_BIAS: GO(EPI_BIAS); }
@@ -884,6 +888,7 @@ static int launch_gemm(const GemmGroup& g, int k, hipStream_t s, bool mt64 = fal
 #undef GO
 #undef GO64
 }
+#ifdef FC_PROBES
 template <int BMo, typename TC, int EPI, int NS>
 static int launch_gemm_d64(const GemmGroup& g, hipStream_t s) {
   const int lds = NS * 24576;
@@ -908,7 +913,6 @@ static int launch_gemm_deep(int kind, int ek, int stages, const GemmGroup& g, hi
 #undef GO_D
   return 1;
 }
-#ifdef FC_PROBES
 // per-(device, stream) scratch of the split-reduction form: partial tiles + one flag per tile (a stream runs one GEMM at a time)
 #define SK_MAX_TILES 512
 static std::mutex g_sk_mu;
@@ -954,8 +958,11 @@ static int launch_gemm_splitk(int kind, int ek, const GemmGroup& g, hipStream_t 
 #endif
 // process-wide form of the under-filled launches (fc_model_set_option FC_OPT_GEMM_FORM; tools build: FC_GEMM_MT64 / FC_GEMM_DEEP64):
 // 0 = 128-row tiles, 64 = 64-row tiles, 3 / 4 = 64-row tiles with a 3- / 4-stage ring
+#ifdef FC_PROBES
 static int g_gemm_form = 0;
 void fc_gemm_set_form(int form) { g_gemm_form = form; }
+#endif
+#ifdef FC_PROBES
 // 64-row tiles exist for these (kind, output type, epilogue) combinations
 static bool gemm_has_mt64(int kind, int dtC, int ek) {
   if (dtC != FC_BF16) return false;
@@ -964,6 +971,7 @@ static bool gemm_has_mt64(int kind, int dtC, int ek) {
   return false;
 }
 
+#endif
 static int gemm_prob_ok(int kind, const GemmProb& p, int N, int K) {
   // vector-width constraints of this kernel; anything else goes to the generic path
   if (p.M <= 0) return 0;
@@ -993,6 +1001,7 @@ int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t 
   }
   g.tiles_n = fc_cdiv(g.N, BN);
   int mt = BM;
+#ifdef FC_PROBES
   {
     // a launch whose 128-row tiles would occupy less than about half of the chip's workgroup slots is cut into 64-row tiles instead
     static const int thr_env = fc_knob("FC_GEMM_MT64", 0);      // (measured: 23.4 / 21.3 against 24.4 / 25.0 us stand-alone, +1 % in the step: off)
@@ -1001,6 +1010,7 @@ int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t 
     for (int i = 0; i < nprob; ++i) t128 += fc_cdiv(g.p[i].M, BM) * g.tiles_n;
     if (thr > 0 && t128 <= thr && gemm_has_mt64(kind, dtC, ek)) mt = 64;
   }
+#endif
 #ifdef FC_PROBES
   {
     // ... or, when its reduction is long (K >= 1 024), computed by two workgroups per tile, half of the k-tiles each (tools build: FC_GEMM_SPLITK=1)
@@ -1016,6 +1026,7 @@ int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t 
     }
   }
 #endif
+#ifdef FC_PROBES
   {
     // ... and when its reduction is long (K >= 1 024: fc2 forward, fc1 / qkv dX of a chain) into 64-row tiles with a deep staging ring, one per workgroup
     static const int deep_env = fc_knob("FC_GEMM_DEEP64", 0);      // stages (3 | 4), 0 = off (stand-alone 24.4 -> 15.2 us, in the step +2 ... +6 %: off)
@@ -1031,6 +1042,7 @@ int fc_gemm_mfma_grouped(int kind, int dtC, GemmGroup g, int nprob, hipStream_t 
       if (r <= 0) return r;
     }
   }
+#endif
   g.tiles0 = fc_cdiv(g.p[0].M, mt) * g.tiles_n;
   g.ntiles = g.tiles0 + (nprob > 1 ? fc_cdiv(g.p[1].M, mt) * g.tiles_n : 0);
   if (nprob == 1) g.p[1] = g.p[0];

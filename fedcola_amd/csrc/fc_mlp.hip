@@ -1,3 +1,4 @@
+#ifdef FC_PROBES      // tools build only (python -m fedcola_amd.build --probes): exact, measured no faster in the step (profiles/r05/fused_mlp.md)
 // Fused MLP for gfx950 (round 5): fc1 -> GELU -> fc2 of a Block (mome.py:117-123) in ONE launch per 64-row panel, and its mirror
 // image in the backward (dh = dm . W2, du = dh * gelu'(u), dx = du . W1).  The hidden activation of a panel never leaves the CU between
 // the two products: per 128-wide hidden chunk, u = X . W1c^T accumulates in registers, goes through the activation into a 16-KB LDS
@@ -476,3 +477,5 @@ int fc_mlp_fused(int bwd, const void* X, const void* Wp, const float* b1, const 
   FC_LAUNCH_CHECK();
   return 0;
 }
+
+#endif  // FC_PROBES

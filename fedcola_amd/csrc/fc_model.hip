@@ -121,19 +121,24 @@ struct fc_model {
   mutable bool step_graph = false;
   // whole-step HIP graphs (fc_client_step): one executable graph per set of buffer addresses and batch shape; the three AdamW constants that
   // change from step to step live in `adamw_dyn` (device) and are rewritten ahead of every replay
-  struct StepKey {
-    const void* p[12]; size_t ws_bytes; int B, n_txt;
+  struct StepKey {      // everything a captured step bakes into its kernel arguments (lr, step and the bias corrections travel through adamw_dyn)
+    const void* p[12]; size_t ws_bytes; int B, n_txt; float beta1, beta2, eps, weight_decay;
     bool operator<(const StepKey& o) const { return memcmp(this, &o, sizeof(StepKey)) < 0; }
   };
   struct StepEntry { int seen = 0; hipGraphExec_t exec = nullptr; bool declined = false; };
+  mutable long step_graph_hits = 0;      // steps that ran as a hipGraphLaunch (tests: a capture that silently declines must be visible)
   mutable std::map<StepKey, StepEntry> step_graphs;
   mutable float* adamw_dyn = nullptr;
+#ifdef FC_PROBES      // the fused MLP and the whole-step graph are tools-build experiments (profiles/r05: exact, not faster in the step)
   size_t mlp_stream_elems() const { return fc_mlp_pack_elems(cfg.dim, cfg.mlp_hidden); }
   size_t mlp_pack_base() const { return ((size_t)total * fc_esize(dt) + 255) / 256 * 256; }      // byte offset of the first stream inside wc
-  size_t mlp_pack_bytes() const { return mlp_fused_ok ? (size_t)2 * cfg.depth * 2 * mlp_stream_elems() * sizeof(bf16_t) : 0; }
+  // streams exist only while the option is on, and only for the towers the model has
+  size_t mlp_pack_bytes() const { return mlp_fused ? (size_t)((tw[0].present ? 1 : 0) + (tw[1].present ? 1 : 0)) * cfg.depth * 2 * mlp_stream_elems() * sizeof(bf16_t) : 0; }
   const bf16_t* mlp_stream(const void* wc, int tower, int layer, int bwd) const {
-    return (const bf16_t*)((const char*)wc + mlp_pack_base()) + ((size_t)(tower * cfg.depth + layer) * 2 + bwd) * mlp_stream_elems();
+    const int slot = (tower == 1 && tw[0].present) ? 1 : 0;
+    return (const bf16_t*)((const char*)wc + mlp_pack_base()) + ((size_t)(slot * cfg.depth + layer) * 2 + bwd) * mlp_stream_elems();
   }
+#endif
   int64_t add(const std::string& name, std::vector<int64_t> shape, int trainable = 1) {
     fc_segment s;
     memset(&s, 0, sizeof(s));
@@ -176,12 +181,14 @@ extern "C" int fc_model_create(const fc_model_cfg* c, fc_model_t** out) {
   bool aux = c->with_aux && uni;                       // mome.py:768
   bool aux_attn = aux && !c->aux_mlp_only, aux_mlp = aux && !c->aux_attn_only;
   m->need_wc = (m->dt == FC_BF16) || aux;
+#ifdef FC_PROBES
   {
-    static const int on = fc_knob("FC_MLP_FUSED", 0), graph = fc_knob("FC_STEP_GRAPH", 0);      // (tools build; the product build takes fc_model_set_option)
+    static const int on = fc_knob("FC_MLP_FUSED", 0), graph = fc_knob("FC_STEP_GRAPH", 0);
     m->mlp_fused_ok = m->dt == FC_BF16 && fc_mlp_fused_ok(c->dim, c->mlp_hidden);
     m->mlp_fused = on && m->mlp_fused_ok;
     m->step_graph = graph != 0;
   }
+#endif
   int present[2] = {c->has_img, c->has_txt};
   // embeddings first (mome.py:709-723)
   for (int i = 0; i < 2; ++i) {
@@ -267,7 +274,9 @@ extern "C" int fc_model_set_trainable(fc_model_t* m, int32_t seg, int32_t traina
   m->segs[seg].trainable = trainable;
   return 0;
 }
-// Run-time switches of a handle (include/fedcola_hip.h: FC_OPT_*).  All default to 0: the measured-fastest forms of the client step.
+#ifdef FC_PROBES
+// Run-time switches of a handle, tools build only (include/fedcola_hip.h: FC_OPT_*): the round-5 experiments that are exact but do not pay in the step.
+extern "C" long fc_dbg_step_graph_hits(const fc_model_t* m) { return m->step_graph_hits; }
 extern "C" int fc_model_set_option(fc_model_t* m, int32_t option, int32_t value) {
   switch (option) {
     case FC_OPT_MLP_FUSED:
@@ -288,9 +297,13 @@ extern "C" int fc_model_set_option(fc_model_t* m, int32_t option, int32_t value)
   }
   FC_REQUIRE(false, "fc_model_set_option: unknown option %d", option);
 }
+#endif
 extern "C" size_t fc_compute_weights_bytes(const fc_model_t* m) {
   if (!m->need_wc) return 0;
-  return m->mlp_fused_ok ? m->mlp_pack_base() + m->mlp_pack_bytes() : (size_t)m->total * fc_esize(m->dt);
+#ifdef FC_PROBES
+  if (m->mlp_fused) return m->mlp_pack_base() + m->mlp_pack_bytes();
+#endif
+  return (size_t)m->total * fc_esize(m->dt);
 }
 
 // ---------------------------------------------------------------- workspace
@@ -515,8 +528,11 @@ static int reparam_table(const fc_model* m, const FcReparam** tab, int* n) {
   return 0;
 }
 static int cached_table(const void* host, size_t bytes, const void** out);
-// the fused MLP's weight streams of every layer of both towers, from the bf16 compute weights in `wc` (one launch)
+// the fused MLP's weight streams of every layer of both towers, from the bf16 compute weights in `wc` (one launch; tools build)
 static int mlp_pack_all(const fc_model* m, void* wc, hipStream_t s) {
+#ifndef FC_PROBES
+  return 0;
+#else
   if (!m->mlp_fused) return 0;      // (a handle that switches the fused MLP on calls fc_prepare_weights next)
   std::vector<FcMlpPackJob> jobs;
   const bf16_t* W = (const bf16_t*)wc;
@@ -530,6 +546,7 @@ static int mlp_pack_all(const fc_model* m, void* wc, hipStream_t s) {
   const void* tab = nullptr;
   FC_TRY(cached_table(jobs.data(), jobs.size() * sizeof(FcMlpPackJob), &tab));
   return fc_mlp_pack(tab, (int)jobs.size(), m->cfg.dim, m->cfg.mlp_hidden, s);
+#endif
 }
 extern "C" int fc_prepare_weights(const fc_model_t* m, const float* params, void* wc, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -800,6 +817,7 @@ static int chain_layer_forward(const Ctx& c, Ws& w, const TowerList& T, int l) {
     ln[q] = LnFwdD{L.xmid, P + b.n2w, P + b.n2b, L.h2, L.mean2, L.rstd2, t.M};
   }
   FC_TRY(ln_fwd_multi(c, ln, nt, D, 1e-5f));
+#ifdef FC_PROBES
   if (m->mlp_fused) {      // fc1 -> GELU -> fc2 + residual in one launch per tower (fc_mlp.hip)
     bool all = true;
     for (int q = 0; q < nt && all; ++q) {
@@ -812,6 +830,7 @@ static int chain_layer_forward(const Ctx& c, Ws& w, const TowerList& T, int l) {
     }
     if (all) return 0;
   }
+#endif
   for (int q = 0; q < nt; ++q) {
     const BlockP& b = m->tw[tw[q]].blocks[l]; TowerWs& t = w.t[tw[q]]; LayerWs& L = t.L[l];
     gd[q] = GemmD{L.h2, c.W(b.fc1.w), L.gact, t.M, GemmEpi()};
@@ -1502,6 +1521,7 @@ static int chain_layer_backward(const Ctx& c, Ws& w, const TowerList& T, int l, 
     gd[q].e.gelu_in = L.u; gd[q].e.gelu_saved_grad = (c.dt == FC_BF16);                 // du = (dm.W2) * gelu'(u)
   }
   bool mlp_done = false;
+#ifdef FC_PROBES
   if (m->mlp_fused) {      // du = (dm . W2) * gelu'(u) (stored: fc1's weight gradient reads it) and dh2 = du . W1 in one launch per tower
     mlp_done = true;
     for (int q = 0; q < nt && mlp_done; ++q) {
@@ -1513,6 +1533,7 @@ static int chain_layer_backward(const Ctx& c, Ws& w, const TowerList& T, int l, 
       mlp_done = r == 0;
     }
   }
+#endif
   if (!mlp_done) FC_TRY(gemm_multi(c, FC_GEMM_NN, gd, nt, Hd, D));
   for (int q = 0; q < nt; ++q) {
     const int i = tw[q];
@@ -2068,6 +2089,9 @@ extern "C" int fc_client_step(const fc_model_t* m, float* params, float* grads, 
     return client_step_impl(m, params, grads, exp_avg, exp_avg_sq, wc, img, ids, labels, B, n_txt, droppath, lr, beta1, beta2, eps, weight_decay, step,
                             lossbuf, workspace, workspace_bytes, stream, nullptr, 0.f, nullptr, 0);
   };
+#ifndef FC_PROBES
+  return eager();
+#else
   if (!m->step_graph || m->dt != FC_BF16) return eager();
   hipStream_t s = (hipStream_t)stream;
   fc_model::StepKey key;
@@ -2075,37 +2099,48 @@ extern "C" int fc_client_step(const fc_model_t* m, float* params, float* grads, 
   const void* ptrs[12] = {params, grads, exp_avg, exp_avg_sq, wc, img, ids, labels, droppath, lossbuf, workspace, stream};
   memcpy(key.p, ptrs, sizeof(ptrs));
   key.B = B; key.n_txt = n_txt; key.ws_bytes = workspace_bytes;
-  if (m->step_graphs.size() >= 16 && !m->step_graphs.count(key)) return eager();      // the addresses keep changing: stay eager
+  key.beta1 = beta1; key.beta2 = beta2; key.eps = eps; key.weight_decay = weight_decay;
+  if (m->step_graphs.size() >= 16 && !m->step_graphs.count(key)) {      // the addresses keep changing (a drop-path table reallocated every step, say)
+    for (auto it = m->step_graphs.begin(); it != m->step_graphs.end();)  // forget the keys that never became a graph; stay eager if all of them did
+      it = it->second.exec ? std::next(it) : m->step_graphs.erase(it);
+    if (m->step_graphs.size() >= 16) return eager();
+  }
   fc_model::StepEntry& e = m->step_graphs[key];
   if (e.declined) return eager();
   const FcAdamW consts = fc_adamw_consts(lr, beta1, beta2, eps, weight_decay, step);
   if (e.exec) {
     FC_TRY(fc_adamw_set_dyn(m->adamw_dyn, consts, s));
     FC_CHECK_HIP(hipGraphLaunch(e.exec, s));
+    ++m->step_graph_hits;
     m->last = LastFwd{workspace, B, n_txt, (m->tw[0].present && m->tw[1].present) ? 1 : 0, droppath, ids};
     return 0;
   }
   if (e.seen < 2) { ++e.seen; return eager(); }
   if (!m->adamw_dyn) FC_CHECK_HIP(hipMalloc(&m->adamw_dyn, 4 * sizeof(float)));
   hipGraph_t graph = nullptr;
-  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e.declined = true; return eager(); }
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e.declined = true; fc_set_error("step graph declined: hipStreamBeginCapture failed"); return eager(); }
   g_step_capture = true;
   const int r = eager();
   g_step_capture = false;
   const hipError_t ce = hipStreamEndCapture(s, &graph);
   if (r != 0 || ce != hipSuccess || !graph) {
+    const std::string why = r == FC_STEP_DECLINED ? std::string("the step's preconditions (fused optimizer, known gradient coverage, every segment trainable)")
+                                                  : (r != 0 ? std::string("error during capture: ") + g_err : std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
     (void)hipGetLastError();
     if (graph) (void)hipGraphDestroy(graph);
     e.declined = true;
+    fc_set_error("step graph declined: %s", why.c_str());
     if (r != 0 && r != FC_STEP_DECLINED) return r;
     return eager();
   }
   const hipError_t ie = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
-  if (ie != hipSuccess) { (void)hipGetLastError(); e.exec = nullptr; e.declined = true; return eager(); }
+  if (ie != hipSuccess) { (void)hipGetLastError(); e.exec = nullptr; e.declined = true; fc_set_error("step graph declined: hipGraphInstantiate: %s", hipGetErrorString(ie)); return eager(); }
   FC_TRY(fc_adamw_set_dyn(m->adamw_dyn, consts, s));
   FC_CHECK_HIP(hipGraphLaunch(e.exec, s));
+  ++m->step_graph_hits;
   return 0;
+#endif
 }
 extern "C" int fc_client_step_prox(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wc, const float* img,
                                    const int64_t* ids, const int64_t* labels, int32_t B, int32_t n_txt, const float* droppath, float lr,
@@ -2441,6 +2476,7 @@ extern "C" int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, f
   FC_CHECK_HIP(hipFree(dev));
   return r;
 }
+#ifdef FC_PROBES
 extern "C" int fc_k_mlp_pack(const void* W1, const void* W2, void* stream_fwd, void* stream_bwd, int32_t D, int32_t Hd, void* stream) {
   FcMlpPackJob job{(const bf16_t*)W1, (const bf16_t*)W2, (bf16_t*)stream_fwd, (bf16_t*)stream_bwd};
   FcMlpPackJob* dev = nullptr;
@@ -2455,6 +2491,7 @@ extern "C" int fc_k_mlp_fused(int32_t bwd, const void* X, const void* Wp, const 
                               const float* rowscale, int32_t rows_per_sample, void* out, int32_t M, int32_t D, int32_t Hd, void* stream) {
   return fc_mlp_fused(bwd, X, Wp, b1, b2, act, gsave, res, rowscale, rows_per_sample, out, M, D, Hd, (hipStream_t)stream);
 }
+#endif
 extern "C" int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd, int32_t step,
                           void* stream) {
   return fc_adamw(p, g, m, v, (size_t)n, lr, beta1, beta2, eps, wd, step, nullptr, 0, (hipStream_t)stream);

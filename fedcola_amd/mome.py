@@ -371,10 +371,13 @@ class ModalityAgnosticTransformer(nn.Module):
         return True
 
     def set_option(self, name: str, value: int):
-        """Run-time switch of the library handle (include/fedcola_hip.h, FC_OPT_*): "mlp_fused" (fc1 -> GELU -> fc2 as one launch per
-        64-row panel), "step_graph" (fc_client_step replays a captured HIP graph), "gemm_form" (process-wide tile form of under-filled
-        launches: 0 | 64 | 3 | 4).  All default to 0, the forms that measure fastest in the ViT-S client step (profiles/r05)."""
+        """Run-time switch of the library handle -- TOOLS BUILD ONLY (FC_PROBES_LIB=1; include/fedcola_hip.h, FC_OPT_*): "mlp_fused" (fc1 -> GELU ->
+        fc2 as one launch per 64-row panel), "step_graph" (fc_client_step replays a captured HIP graph), "gemm_form" (process-wide tile form of
+        under-filled launches: 0 | 64 | 3 | 4).  The round-5 experiments: exact, no faster in the ViT-S client step (profiles/r05), not in the product."""
         code = {"mlp_fused": _lib.FC_OPT_MLP_FUSED, "step_graph": _lib.FC_OPT_STEP_GRAPH, "gemm_form": _lib.FC_OPT_GEMM_FORM}[name]
+        if not _lib.is_probes_build():
+            raise _lib.FedcolaHipError(f"set_option({name!r}): the product library has no run-time options; the experiments live in the tools build "
+                                       "(python -m fedcola_amd.build --probes, FC_PROBES_LIB=1)")
         check(_lib.lib().fc_model_set_option(self._handle.h, code, int(value)))
         opts = self.__dict__.setdefault("_options", {})
         opts[name] = int(value)
@@ -401,7 +404,7 @@ class ModalityAgnosticTransformer(nn.Module):
         nbytes = int(L.fc_compute_weights_bytes(self._handle.h))
         if nbytes == 0:
             return
-        if self._wc is None or self._wc.device != self.flat.device:
+        if self._wc is None or self._wc.device != self.flat.device or self._wc.numel() < nbytes:      # (grows when a tools-build option adds packed streams)
             self._wc = torch.empty(nbytes, dtype=torch.uint8, device=self.flat.device)
             force = True
         if force or self._wc_version != self.flat._version:

@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 5   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw;
+#define FC_ABI_VERSION 6   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw;
                               4: fc_image_u8_to_f32, fc_k_gemm_epi; fc_k_layernorm_partial_floats counts fp64 rows;
-                              5: fc_k_mlp_pack, fc_k_mlp_fused, fc_model_set_option */
+                              5: fc_k_mlp_pack, fc_k_mlp_fused, fc_model_set_option;
+                              6: those three left the product library: they exist in the tools build only (#ifdef FC_PROBES below) */
 
 enum { FC_PREC_FP32 = 0, FC_PREC_BF16 = 1 };
 enum { FC_TASK_NONE = 0, FC_TASK_CLS = 1, FC_TASK_RTV = 2 };
@@ -71,16 +72,6 @@ int64_t fc_model_num_params(const fc_model_t* m);        /* padded flat length i
 int32_t fc_model_num_segments(const fc_model_t* m);
 int fc_model_segment(const fc_model_t* m, int32_t i, fc_segment* out);
 int fc_model_set_trainable(fc_model_t* m, int32_t seg, int32_t trainable);  /* fedavgserver.py:422-429 freeze */
-/* Run-time switches (round 5).  Every option defaults to 0 = the forms that measure fastest in the ViT-S client step; the others are kept
- * selectable because they are the better kernels stand-alone (profiles/r05): same results to the bit (FC_OPT_MLP_FUSED, FC_OPT_STEP_GRAPH)
- * or to the last fp32 bits of a sum whose order does not change (FC_OPT_GEMM_FORM never changes a result: same k order per element).
- *  FC_OPT_MLP_FUSED  1: fc1 -> GELU -> fc2 (and the backward mirror) as one launch per 64-row panel (bf16 mode, dim 384).  Call
- *                       fc_prepare_weights after switching it on (the fused kernels read packed weight streams behind the compute weights).
- *  FC_OPT_STEP_GRAPH 1: fc_client_step replays a captured HIP graph from the third step with the same buffers and shapes on.
- *  FC_OPT_GEMM_FORM  process-wide: tiles of the NT / NN launches that would fill less than half of the chip: 0 = 128 x 128, 64 = 64 x 128,
- *                       3 | 4 = 64 x 128 with a 3- / 4-stage staging ring for K >= 1024. */
-enum { FC_OPT_MLP_FUSED = 1, FC_OPT_STEP_GRAPH = 2, FC_OPT_GEMM_FORM = 3 };
-int fc_model_set_option(fc_model_t* m, int32_t option, int32_t value);
 
 /* The library's auxiliary HIP stream (hipStream_t as void*) that carries the text tower.  It idles for most of a step, so the
  * host->device copy of the NEXT batch belongs there (fedcola_amd/loaders/prefetch.py): the GPU runs at most four hardware
@@ -285,6 +276,29 @@ int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, const void* o,
  * 3 = the fp32 mode's form: dY, X are FP32, products by split-operand MFMAs, the row reduction cut into slices added in fp64, and db is ADDED TO.
  * Test entry point: allocates its one-entry problem table and synchronises the stream. */
 int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, float* db, int32_t rows, int32_t out, int32_t in, void* stream);
+int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+               int32_t step, void* stream);
+int fc_k_cast(int32_t dt_out, const float* src, void* dst, int64_t n, void* stream);
+/* sims[nq,ng] = q . g^T in float64 (v_mfma_f64_16x16x4_f64) */
+int fc_k_sim_f64(const double* q, const double* g, double* sims, int32_t nq, int32_t ng, int32_t d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------------------------
+ * TOOLS BUILD ONLY (libfedcola_hip_probes.so: python -m fedcola_amd.build --probes, compiled with -DFC_PROBES; chosen by FC_PROBES_LIB=1 in
+ * tools/ and in the tests that cover it).  The product library does not export what follows: experiments that are exact but measured no
+ * faster in the client step (profiles/r05), kept buildable with their tests. */
+#ifdef FC_PROBES
+/* Run-time switches of the round-5 experiments.  Every option defaults to 0 = the forms that measure fastest in the ViT-S client step; the others are
+ * the better kernels stand-alone and no faster in the step (profiles/r05): same results to the bit (FC_OPT_MLP_FUSED, FC_OPT_STEP_GRAPH)
+ * or to the last fp32 bits of a sum whose order does not change (FC_OPT_GEMM_FORM never changes a result: same k order per element).
+ *  FC_OPT_MLP_FUSED  1: fc1 -> GELU -> fc2 (and the backward mirror) as one launch per 64-row panel (bf16 mode, dim 384).  Call
+ *                       fc_prepare_weights after switching it on (the fused kernels read packed weight streams behind the compute weights).
+ *  FC_OPT_STEP_GRAPH 1: fc_client_step replays a captured HIP graph from the third step with the same buffers and shapes on.
+ *  FC_OPT_GEMM_FORM  process-wide: tiles of the NT / NN launches that would fill less than half of the chip: 0 = 128 x 128, 64 = 64 x 128,
+ *                       3 | 4 = 64 x 128 with a 3- / 4-stage staging ring for K >= 1024. */
+enum { FC_OPT_MLP_FUSED = 1, FC_OPT_STEP_GRAPH = 2, FC_OPT_GEMM_FORM = 3 };
+int fc_model_set_option(fc_model_t* m, int32_t option, int32_t value);
+/* steps of this handle that ran as a hipGraphLaunch (FC_OPT_STEP_GRAPH) */
+long fc_dbg_step_graph_hits(const fc_model_t* m);
 /* the fused MLP of a Block (mome.py:117-123), bf16, D = 384, Hd % 128 == 0, one launch per call; returns 1 when the shape is not covered.
  * The weights are read from a copy packed in MFMA-fragment order: fc_k_mlp_pack writes both directions' streams (2 * D * Hd bf16 each) from
  * the row-major W1 [Hd,D] and W2 [D,Hd] (test entry point: allocates its one-entry job table and synchronises the stream).
@@ -295,11 +309,7 @@ int fc_k_dw(int32_t wide, const void* dY, const void* X, float* dW, float* db, i
 int fc_k_mlp_pack(const void* W1, const void* W2, void* stream_fwd, void* stream_bwd, int32_t D, int32_t Hd, void* stream);
 int fc_k_mlp_fused(int32_t bwd, const void* X, const void* Wp, const float* b1, const float* b2, void* act, void* gsave, const void* res,
                    const float* rowscale, int32_t rows_per_sample, void* out, int32_t M, int32_t D, int32_t Hd, void* stream);
-int fc_k_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
-               int32_t step, void* stream);
-int fc_k_cast(int32_t dt_out, const float* src, void* dst, int64_t n, void* stream);
-/* sims[nq,ng] = q . g^T in float64 (v_mfma_f64_16x16x4_f64) */
-int fc_k_sim_f64(const double* q, const double* g, double* sims, int32_t nq, int32_t ng, int32_t d, void* stream);
+#endif /* FC_PROBES */
 
 #ifdef __cplusplus
 }

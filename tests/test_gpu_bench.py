@@ -104,5 +104,24 @@ def test_bench_single_gpu_line_carries_the_contract_and_the_reported_legs():
     assert rec["n_gpus"] == 1 and rec["steps"] == 8 and rec["dtype"] == "bf16" and rec["vs_baseline"] is None and "workload" in rec["config"]
     assert abs(rec["value"] - 64 / (rec["ms_per_step"] * 1e-3)) <= 0.01 * rec["value"]
     assert rec["dropout_0p1"]["ms_per_step"] > 0 and rec["sustained"]["seconds"] >= 5
+    # the legs that match how the reference is run (scripts/flickr.sh: --B 112 --E 5; a --with_aux uni-modal client of a FedCola run)
+    cr, c112, caux = rec["client_round"], rec["client_round_b112_e5"], rec["client_round_img_aux"]
+    assert cr["ms_per_step"] > 0 and "error" not in c112 and "error" not in caux, (c112, caux)
+    assert c112["B"] == 112 and c112["E"] == 5 and c112["steps_per_round"] == 40 and c112["ms_per_step"] > cr["ms_per_step"]
+    assert caux["unit"] == "images/s" and 0.0 <= caux["acc1"] <= 1.0 and caux["ms_per_step"] > 0
     f32 = rec["fp32_mode"]
     assert f32["dtype"] == "fp32" and rec["ms_per_step"] < f32["ms_per_step"] < 100.0
+
+
+def test_bench_keeps_its_line_when_the_cabi_communicator_cannot_be_created(tmp_path):
+    """N > 1 with fc_comm_create failing on every rank (as a missing librccl would): the run continues on torch.distributed's all-reduce, the
+    line says which path aggregated and why (cabi_comm_error), and still validates itself."""
+    d = str(tmp_path / "dump")
+    env = dict(os.environ, FC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", FC_BENCH_INJECT_COMM_FAILURE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline", "--agg", "cabi", "--dump-agg", d]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert "injected failure" in rec["cabi_comm_error"] and rec["aggregate_path"].startswith("HIP blend + torch.distributed.all_reduce")
+    assert rec["rccl_world"] == 2 and rec["dist_backend"] in ("gloo", "nccl") and rec["rccl_version"]
+    assert rec["agg_all_ranks_equal"] is True and rec["agg_slice_recomputed_ok"] is True

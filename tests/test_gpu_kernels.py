@@ -233,6 +233,7 @@ def _bf(t):
     return t.to(torch.bfloat16).double()
 
 
+@pytest.mark.probes
 @pytest.mark.parametrize("M", [64, 197, 333, 197 * 22, 2048])      # ragged last panel, one full-size chain, the text tower
 @pytest.mark.parametrize("Hd", [1536, 256])
 @pytest.mark.parametrize("rowscale", [False, True])

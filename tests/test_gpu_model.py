@@ -1,4 +1,5 @@
 """Model-level parity on the GPU: the HIP client step (through the C ABI) against the oracle and the golden vectors."""
+import os
 import pytest
 import torch
 
@@ -261,6 +262,7 @@ def test_colearn_attn_d384_bf16_shared_attention_gradients(B):
     assert "blockses.1.0.attn.qkv.weight" not in grads
 
 
+@pytest.mark.probes
 @pytest.mark.parametrize("B", [16, 32])
 def test_step_graph_replay_is_bit_identical_to_the_eager_step(B):
     """fc_client_step replays a captured HIP graph from the third step with the same buffers on (fc_model.hip: whole-step graph).  From one
@@ -286,9 +288,13 @@ def test_step_graph_replay_is_bit_identical_to_the_eager_step(B):
     ws = model.workspace(B, 16)
     P, L = _lib.ptr, _lib.lib()
 
-    def step(k, lr, lossbuf):
-        _lib.check(L.fc_client_step(model._handle.h, P(model.flat), P(st["g"]), P(st["m"]), P(st["v"]), P(model._wc_or_flat()), P(img), P(ids), None, B, 16,
-                                    None, lr, 0.9, 0.999, 1e-8, 0.01, k, P(lossbuf), P(ws), ws.numel(), _lib.stream_ptr()))
+    own = torch.cuda.Stream()      # a stream capture cannot begin on the legacy default stream (the capture then declines: what ADVICE r05 suspected)
+    torch.cuda.synchronize()
+
+    def step(k, lr, lossbuf, b1=0.9, b2=0.999):
+        with torch.cuda.stream(own):
+            _lib.check(L.fc_client_step(model._handle.h, P(model.flat), P(st["g"]), P(st["m"]), P(st["v"]), P(model._wc_or_flat()), P(img), P(ids), None, B, 16,
+                                        None, lr, b1, b2, 1e-8, 0.01, k, P(lossbuf), P(ws), ws.numel(), _lib.stream_ptr()))
         torch.cuda.synchronize()
 
     def snapshot():
@@ -323,8 +329,16 @@ def test_step_graph_replay_is_bit_identical_to_the_eager_step(B):
         assert n_lin > 0.8 * n
     # the replayed step really used lr = 3e-3 at step 7, not the captured 1e-3 at step 3
     assert not torch.equal(outs["captured"]["p"], outs["replay"]["p"])
+    # ... and the steps that were meant to be graph launches WERE: the capture (1) and the two replays; a capture that silently declines would
+    # pass every comparison above on eager steps
+    assert int(L.fc_dbg_step_graph_hits(model._handle.h)) == 3, L.fc_last_error()
+    # other betas are another graph: the captured kernels bake them in (the key holds them since round 6)
+    restore(s0)
+    step(7, 3e-3, loss_a, b1=0.8, b2=0.99)
+    assert int(L.fc_dbg_step_graph_hits(model._handle.h)) == 3 and not torch.equal(model.flat.detach(), outs["replay"]["p"])
 
 
+@pytest.mark.probes
 @pytest.mark.parametrize("option,value", [("mlp_fused", 1), ("gemm_form", 64), ("gemm_form", 3), ("gemm_form", 4)])
 def test_optional_kernel_forms_give_the_same_step(option, value):
     """The forms fc_model_set_option switches on (fused MLP, 64-row GEMM tiles with or without the deep staging ring) are other schedules of
@@ -370,3 +384,34 @@ def test_optional_kernel_forms_give_the_same_step(option, value):
                 assert float((x - y).abs().max()) <= 2e-3 * max(float(x.abs().max()), 1e-12), f"{key} of {name}"
         n_lin += c if linear else 0
     assert n_lin > 0.8 * a["p"].numel()
+
+
+def test_the_product_library_has_no_run_time_options():
+    """the experiments that do not pay (fused MLP, 64-row / ring / split GEMM forms, whole-step graph) left the product
+    library; set_option says where they went instead of silently doing nothing."""
+    import product_util as PU
+    from fedcola_amd import _lib
+    if _lib.is_probes_build():
+        pytest.skip("running on the tools build")
+    rec = G.load("model_toy.json")
+    model = PU.build_product(rec["mk"], "fp32", G.case_weights("toy"))
+    for name in ("mlp_fused", "step_graph", "gemm_form"):
+        with pytest.raises(_lib.FedcolaHipError, match="tools build"):
+            model.set_option(name, 1)
+    assert not hasattr(_lib.lib(), "fc_k_mlp_fused") and not hasattr(_lib.lib(), "fc_model_set_option")
+
+
+def test_tools_build_experiments():
+    """The tests marked `probes` (fused MLP kernel and in-model form, GEMM forms, whole-step graph replay incl. its hit counter) against
+    libfedcola_hip_probes.so, in a child process (FC_PROBES_LIB is read when fedcola_amd._lib is imported)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "fedcola_amd", "libfedcola_hip_probes.so")):
+        pytest.skip("tools build absent (python -m fedcola_amd.build --probes)")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu and probes", os.path.join(root, "tests", "test_gpu_model.py"),
+                        os.path.join(root, "tests", "test_gpu_kernels.py")], env=dict(os.environ, FC_PROBES_LIB="1"), capture_output=True, text=True,
+                       timeout=1500, cwd=root)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0, tail + r.stderr[-1500:]
+    assert " passed" in tail and "failed" not in tail, tail

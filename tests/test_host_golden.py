@@ -176,13 +176,25 @@ def test_fedprox_update_oracle_vs_golden():
 def test_c_abi_exports_every_declared_symbol():
     from fedcola_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "fedcola_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(fc_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(declared) >= 25
+    # the `#ifdef FC_PROBES` block declares what only the tools build exports (the round-5 experiments): checked against that library
+    m = re.search(r"#ifdef FC_PROBES\n(.*?)#endif /\* FC_PROBES \*/", hdr, re.S)
+    assert m, "the header's tools-build block is gone"
+    product_hdr = hdr.replace(m.group(0), "")
+    declared = sorted(set(re.findall(r"\b(fc_[a-z0-9_]+)\s*\(", product_hdr)))
+    probes_only = sorted(set(re.findall(r"\b(fc_[a-z0-9_]+)\s*\(", m.group(1))))
+    assert len(declared) >= 25 and set(probes_only) == set(_lib.PROBES_SIGNATURES), probes_only
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fedcola_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.fc_abi_version() == 5
+    for name in probes_only:
+        assert not hasattr(lib, name), f"{name} is a tools-build experiment and must not be exported by the product library"
+    assert lib.fc_abi_version() == 6
+    probes = os.path.join(os.path.dirname(_lib.LIB_PATH), "libfedcola_hip_probes.so")
+    if os.path.exists(probes):
+        pl = ctypes.CDLL(probes)
+        for name in declared + probes_only:
+            assert hasattr(pl, name), f"{name} missing from the tools build"
 
 
 def test_model_layout_and_errors_without_gpu():
@@ -210,7 +222,7 @@ def test_header_is_plain_c(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     src = tmp_path / "t.c"
-    src.write_text('#include "fedcola_hip.h"\nint main(void) { fc_model_cfg c; (void)c; return FC_ABI_VERSION == 3 ? 0 : 1; }\n')
+    src.write_text('#include "fedcola_hip.h"\nint main(void) { fc_model_cfg c; (void)c; return FC_ABI_VERSION == 6 ? 0 : 1; }\n')
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

@@ -5,6 +5,7 @@ stores, fc2 / proj: bias + residual, fc2-dX: times the saved gelu').  Device-sid
     rocprofv3 --kernel-trace --output-format csv -d DIR -o g -- python3 tools/cold_bench.py [rows] [reps]
 and summarise with tools/ktrace.py, or read the HIP-event times this script prints (launch gaps included: upper bounds).
 rows: 12608 (full batch), 4334 (a third: one of three image chains), 2048 (text tower)."""
+import os as _os; _os.environ.setdefault("FC_PROBES_LIB", "1")      # the fused-MLP entry points live in the tools build
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -10,6 +10,7 @@ for the backward -- gelu, gelu', qkv, h1, h2, xmid, x -- the proxy 4 992), leave
 (2 304 instead of 1 536 activations per row).  Printed beside it: the MLP as it is (hidden 1 536) and the six separate kernels the stage
 would replace, all under the cold protocol of tools/cold_bench.py (every launch on another buffer set).
     python tools/rowlocal_proxy.py [rows]          (HIP events; run under rocprofv3 --kernel-trace for device-side durations)"""
+import os as _os; _os.environ.setdefault("FC_PROBES_LIB", "1")      # the fused-MLP entry points live in the tools build
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
