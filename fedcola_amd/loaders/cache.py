@@ -107,10 +107,12 @@ class DecodedCache(Dataset):
     @classmethod
     def applicable(cls, dataset, probe_samples: int = 3, probe_repeats: int = 4) -> bool:
         """A caption dataset (image_key) whose samples are a pure function of the index.  Decided from the transform chain: any Random* /
-        ColorJitter / Auto-augment member refuses (the client keeps the reference's loader); a chain of known deterministic transforms
-        (the reference's --resize / --imnorm: Resize, ToTensor, Normalize) accepts without fetching anything.  Only chains with members that
-        cannot be judged by name (torchvision's Lambda -- the reference pads its chains with identity Lambdas -- or user callables) are
-        probed: `probe_samples` samples fetched `probe_repeats` times each must come back identical (one pair of fetches, as in round 4,
+        ColorJitter / Auto-augment member refuses without fetching anything (the client keeps the reference's loader).  Every other dataset is
+        PROBED -- the names only set how hard: a chain of known deterministic transforms (the reference's --resize / --imnorm: Resize, ToTensor,
+        Normalize) fetches ONE sample twice, because randomness can also sit outside `transform` (a target_transform, a random choice inside
+        __getitem__, a subclass that reuses a deterministic name); chains with members that cannot be judged by name (torchvision's Lambda --
+        the reference pads its chains with identity Lambdas -- or user callables) fetch `probe_samples` samples `probe_repeats` times each.
+        Image AND token tensors must come back identical (one pair of fetches alone, as in round 4,
         passes a RandomHorizontalFlip(0.5) every second time and then freezes ONE augmented view per image), with the torch / numpy / python
         RNG states saved before and restored after, so that a probe never shifts the shuffle or augmentation stream of the run."""
         base, _ = _resolve(dataset)
@@ -124,13 +126,14 @@ class DecodedCache(Dataset):
         try:
             n = len(dataset)
             picks = sorted({0, n // 2, n - 1})[:max(1, probe_samples)] if verdict == "unknown" else [0]
-            reps = probe_repeats if verdict == "unknown" else 1
+            reps = probe_repeats if verdict == "unknown" else 2
             for i in picks:
                 a = dataset[i]
                 if not (torch.is_tensor(a[0]) and a[0].dtype == torch.float32 and a[0].dim() == 3 and torch.is_tensor(a[1])):
                     return False
                 for _ in range(reps - 1):
-                    if not torch.equal(a[0], dataset[i][0]):
+                    b = dataset[i]
+                    if not (torch.equal(a[0], b[0]) and torch.is_tensor(b[1]) and torch.equal(a[1], b[1])):
                         return False
             return True
         except Exception:                              # unreadable data: let the ordinary loader raise where the reference would

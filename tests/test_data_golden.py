@@ -387,10 +387,20 @@ def test_decoded_cache_applicability_is_decided_from_the_transform_chain(tmp_pat
         verdicts.append(DecodedCache.applicable(hidden))
         assert same(s0, states())
     assert sum(verdicts) <= 1                        # 3 samples x 4 fetches: all agree with probability 2^-9 per call
-    # (3) known deterministic names only: accepted on the structure plus ONE sample's type check, no repeated fetches
+    # (3) known deterministic names only: still probed, lightly -- ONE sample fetched twice (randomness can sit outside `transform`)
     calls.clear()
     det = Counting(root, split="train", transform=Compose([ToTensor()]), tokenizer=_tok, max_length=8)
-    assert DecodedCache.applicable(det) and len(calls) == 1
+    assert DecodedCache.applicable(det) and calls == [0, 0]
+    # (3b) ... which is what catches a dataset whose CAPTION choice is random although its transform chain is all deterministic names
+    class RandomCaption(Flickr30kCap):
+        def __getitem__(self, i):
+            s = list(super().__getitem__(i))
+            s[1] = s[1].clone()
+            s[1][1] = int(torch.randint(5, 25, (1,)))
+            return tuple(s)
+    rc = RandomCaption(root, split="train", transform=Compose([ToTensor()]), tokenizer=_tok, max_length=8)
+    s0 = states()
+    assert sum(DecodedCache.applicable(rc) for _ in range(10)) <= 2 and same(s0, states())
     # (4) an unknown but deterministic callable (the reference pads its chains with identity Lambdas): accepted after the probe
     calls.clear()
     lam = Counting(root, split="train", transform=lambda im: base(im), tokenizer=_tok, max_length=8)
