@@ -697,11 +697,136 @@ __global__ void __launch_bounds__(256) k_con_grads(const float* __restrict__ a, 
     dst[d] = s;
   }
 }
+// ---- two-launch form (round 6; D % 4 == 0): the loss phase sits between the forward's join and the backward's fork with the chip empty, so
+// every launch and every boundary in it is step time.  Launch 1, block i: row i of L AND column i of L (row i of L^T: tau <a_j, b_i>) from the
+// inputs alone, so that both log-sum-exps of index i and its loss terms are local to the block -- no pass over L in between.  Launch 2: the
+// gradients, with the column case reading L^T rows (contiguous) and the D range cut into float4 columns x o-groups so that all loads of a thread
+// are independent.  Same sums as the three-kernel form up to the order of the fp32 adds.
+__global__ void __launch_bounds__(256) k_con_rowcol(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ L, float* __restrict__ LT,
+                                                    float* __restrict__ lse_r, float* __restrict__ lse_c, float* lossbuf, int B, int D, float tau) {
+  extern __shared__ float sh[];      // row[B] | col[B]
+  float* rowv = sh; float* colv = rowv + B;
+  const int i = blockIdx.x, t = threadIdx.x, q = t & 3, nc = D >> 2;
+  const float4* ai = (const float4*)(a + (size_t)i * D);      // the same address for every lane of a quarter: one broadcast request
+  const float4* bi = (const float4*)(b + (size_t)i * D);
+  for (int j0 = 0; j0 < B; j0 += 64) {
+    const int j = j0 + (t >> 2);
+    float s1 = 0.f, s2 = 0.f;
+    if (j < B) {
+      const float4* bj = (const float4*)(b + (size_t)j * D);
+      const float4* aj = (const float4*)(a + (size_t)j * D);
+      int c = q;
+      for (; c + 28 < nc; c += 32) {      // eight chunks of each of the four rows per batch: 32 independent 16-byte loads, one round trip, then their FMAs
+        float4 x[8], y[8], u[8], v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { x[k] = bj[c + 4 * k]; y[k] = aj[c + 4 * k]; u[k] = ai[c + 4 * k]; v[k] = bi[c + 4 * k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          s1 = fmaf(u[k].x, x[k].x, s1); s1 = fmaf(u[k].y, x[k].y, s1); s1 = fmaf(u[k].z, x[k].z, s1); s1 = fmaf(u[k].w, x[k].w, s1);
+          s2 = fmaf(y[k].x, v[k].x, s2); s2 = fmaf(y[k].y, v[k].y, s2); s2 = fmaf(y[k].z, v[k].z, s2); s2 = fmaf(y[k].w, v[k].w, s2);
+        }
+      }
+      for (; c < nc; c += 4) {
+        const float4 x = bj[c], y = aj[c], u = ai[c], v = bi[c];
+        s1 = fmaf(u.x, x.x, s1); s1 = fmaf(u.y, x.y, s1); s1 = fmaf(u.z, x.z, s1); s1 = fmaf(u.w, x.w, s1);
+        s2 = fmaf(y.x, v.x, s2); s2 = fmaf(y.y, v.y, s2); s2 = fmaf(y.z, v.z, s2); s2 = fmaf(y.w, v.w, s2);
+      }
+    }
+    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+    if (q == 0 && j < B) {
+      const float l1 = tau * s1, l2 = tau * s2;
+      rowv[j] = l1; colv[j] = l2;
+      L[(size_t)i * B + j] = l1; LT[(size_t)i * B + j] = l2;
+    }
+  }
+  __syncthreads();
+  const int wave = t >> 6, lane = t & 63;
+  if (wave < 2) {
+    const float* v = wave == 0 ? rowv : colv;
+    float mx = -INFINITY;
+    for (int j = lane; j < B; j += 64) mx = fmaxf(mx, v[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < B; j += 64) sum += expf(v[j] - mx);
+    sum = wave_sum(sum);
+    const float lse = mx + logf(sum);
+    if (lane == 0) {
+      (wave == 0 ? lse_r : lse_c)[i] = lse;
+      const float contrib = 0.5f * (lse - rowv[i]) / (float)B;      // L_ii is the diagonal of both
+      atomicAdd(lossbuf + 1, contrib);
+      atomicAdd(lossbuf + 0, contrib * (float)B);
+    }
+  }
+}
+// blocks [0, B): da_r = sum_j dL_rj b_j ; blocks [B, 2B): db_r = sum_i dL_ir a_i ; dL formed on the fly (times tau).  G o-groups x nc float4 columns.
+__global__ void __launch_bounds__(256) k_con_grads2(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ L,
+                                                    const float* __restrict__ LT, const float* __restrict__ lse_r, const float* __restrict__ lse_c,
+                                                    float* __restrict__ da, float* __restrict__ db, int B, int D, float tau, int G) {
+  extern __shared__ float sh[];      // w[B] | partial sums [G][D]
+  float* w = sh; float4* part = (float4*)(sh + ((B + 3) & ~3));
+  const bool isrow = blockIdx.x < (unsigned)B;
+  const int r = isrow ? blockIdx.x : blockIdx.x - B, t = threadIdx.x, nc = D >> 2;
+  const float c0 = (0.5f / (float)B) * tau;
+  for (int o = t; o < B; o += 256) {
+    const float l = (isrow ? L : LT)[(size_t)r * B + o];
+    const float e1 = isrow ? expf(l - lse_r[r]) : expf(l - lse_r[o]);
+    const float e2 = isrow ? expf(l - lse_c[o]) : expf(l - lse_c[r]);
+    w[o] = c0 * (e1 + e2 - (o == r ? 2.0f : 0.0f));
+  }
+  __syncthreads();
+  const float4* src = (const float4*)(isrow ? b : a);
+  for (int c0i = 0; c0i < nc; c0i += 256 / G) {      // (one pass when G * nc <= 256: D = 384 -> nc = 96, G = 2)
+    const int g = t / (256 / G), c = c0i + t % (256 / G);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nc && c - c0i < 256 / G) {
+      int o = g;
+      for (; o + 7 * G < B; o += 8 * G) {      // eight independent loads in flight
+        float4 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = src[(size_t)(o + k * G) * nc + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float wo = w[o + k * G];
+          acc.x = fmaf(wo, x[k].x, acc.x); acc.y = fmaf(wo, x[k].y, acc.y); acc.z = fmaf(wo, x[k].z, acc.z); acc.w = fmaf(wo, x[k].w, acc.w);
+        }
+      }
+      for (; o < B; o += G) {
+        const float4 x = src[(size_t)o * nc + c];
+        const float wo = w[o];
+        acc.x = fmaf(wo, x.x, acc.x); acc.y = fmaf(wo, x.y, acc.y); acc.z = fmaf(wo, x.z, acc.z); acc.w = fmaf(wo, x.w, acc.w);
+      }
+      part[g * nc + c] = acc;
+    }
+  }
+  __syncthreads();
+  float4* dst = (float4*)((isrow ? da : db) + (size_t)r * D);
+  for (int c = t; c < nc; c += 256) {
+    float4 s4 = part[c];
+    for (int g = 1; g < G; ++g) { const float4 p = part[g * nc + c]; s4.x += p.x; s4.y += p.y; s4.z += p.z; s4.w += p.w; }
+    dst[c] = s4;
+  }
+}
 int fc_contrastive_fwd_bwd(const float* a, const float* b, int B, int D, float tau, float* scratch, float* lossbuf, float* da, float* db,
                            hipStream_t s) {
   float* L = scratch;
+  float* LT = scratch + (size_t)B * B;
   float* lse_r = scratch + 2 * (size_t)B * B;
   float* lse_c = lse_r + B;
+  const bool al = !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)da | (uintptr_t)db) & 15);
+  if ((D & 3) == 0 && al && (size_t)(2 * D + 2 * B) * sizeof(float) <= 60000) {
+    const int nc = D >> 2;
+    int G = 256 / nc;                                   // o-groups of the gradient launch: as many as fit the block, at most 8
+    G = G < 1 ? 1 : (G > 8 ? 8 : G);
+    while (256 % G) --G;
+    const size_t lds2 = sizeof(float) * (((size_t)B + 3) & ~(size_t)3) + sizeof(float) * (size_t)G * D;
+    if (lds2 <= 60000) {
+      hipLaunchKernelGGL(k_con_rowcol, dim3(B), dim3(256), sizeof(float) * (2 * B), s, a, b, L, LT, lse_r, lse_c, lossbuf, B, D, tau);
+      hipLaunchKernelGGL(k_con_grads2, dim3(2 * B), dim3(256), lds2, s, a, b, L, LT, lse_r, lse_c, da, db, B, D, tau, G);
+      FC_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL(k_con_logits, dim3(B), dim3(256), 0, s, a, b, L, B, D, tau);
   hipLaunchKernelGGL(k_con_lse, dim3(2 * B), dim3(64), 0, s, L, lse_r, lse_c, lossbuf, B);
   hipLaunchKernelGGL(k_con_grads, dim3(2 * B), dim3(256), sizeof(float) * B, s, a, b, L, lse_r, lse_c, da, db, B, D, tau);
