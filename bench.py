@@ -32,7 +32,7 @@ PAIR_GFLOP = 31.61           # algorithmic GEMM FLOPs per img-txt pair fwd+bwd, 
 STEP_ALG_GB = 10.8           # algorithmic HBM bytes per B=64 step, fully fused bf16
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r06")
 
 
 class Args:
@@ -137,7 +137,7 @@ def gemm_roofline(steps=200):
         if rec.get("shape") == [ROOF_KIND, M, N, K] and rec.get("us_per_launch"):
             out["rocprof_us_per_launch"] = rec["us_per_launch"]
             out["frac_rocprof"] = round(flops / (rec["us_per_launch"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4)
-            out["rocprof_source"] = rec.get("source", "profiles/r05/roofline_kernel_stats.csv") + (
+            out["rocprof_source"] = rec.get("source", "profiles/r06/roofline_kernel_stats.csv") + (
                 "" if rec.get("source_stamp") == kernel_source_stamp() else " (measured on earlier kernel sources)")
     if note:
         out["traffic_note"] = note

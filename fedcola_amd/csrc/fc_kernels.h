@@ -26,7 +26,11 @@ struct FcLnBwdP {
   const void* dy; const void* x; const float* mean; const float* rstd; const float* g; const void* res; void* dx; void* dx_scaled;
   const float* rowscale; fc_ln_part_t* partial; int rows_per_sample; int M; int blk0; int pad;
 };
-struct FcLnBwdArgs { FcLnBwdP p[2]; int nprob; int D; };
+struct FcLnBwdArgs { FcLnBwdP p[2]; int nprob; int D; 
+#ifdef FC_PROBES
+  int skip_partials;
+#endif
+};
 int fc_layernorm_grouped_ok(int D);
 int fc_layernorm_fwd_grouped(int dt, FcLnFwdArgs a, hipStream_t s);
 int fc_layernorm_bwd_grouped(int dt, FcLnBwdArgs a, hipStream_t s);

@@ -212,6 +212,9 @@ __global__ void __launch_bounds__(256) k_ln_bwd_g(FcLnBwdArgs a) {
       }
     }
   }
+#ifdef FC_PROBES
+  if (a.skip_partials) return;      // measurement only (FC_LN_NOPART=1): what the column-sum tail costs; dgamma / dbeta are wrong
+#endif
   // column sums: the four row slots of the wave (lanes l, l+16, l+32, l+48 hold the same columns), then the four waves through LDS
 #pragma unroll
   for (int t = 0; t < CH; ++t) {
@@ -314,6 +317,10 @@ int fc_layernorm_bwd_grouped(int dt, FcLnBwdArgs a, hipStream_t s) {
   }
   if (blocks == 0) return 0;
   const int ch = fc_cdiv(a.D / 8, 16);
+#ifdef FC_PROBES
+  static const int nopart = fc_knob("FC_LN_NOPART", 0);
+  a.skip_partials = nopart;
+#endif
   const size_t lds = (dt == FC_F32 ? sizeof(double) : sizeof(float)) * 8 * a.D;
 #define GO(CHN)                                                                                                     \
   do {                                                                                                              \

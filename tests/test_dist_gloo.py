@@ -176,3 +176,44 @@ def test_creamfl_public_features_are_exchanged_between_ranks():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _uid_fail_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fedcola_amd.comm import Comm
+
+        def boom():
+            raise RuntimeError("librccl.so could not be loaded")
+        Comm.unique_id = staticmethod(boom)              # what a node without RCCL does on rank 0
+        try:
+            Comm.from_torch_dist()
+            q.put((rank, "FAIL: no exception"))
+        except RuntimeError as e:
+            q.put((rank, "ok" if "rank 0 could not create an RCCL id" in str(e) and "librccl" in str(e) else f"FAIL: {e}"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failed_rccl_id_on_rank_0_raises_on_every_rank_instead_of_hanging_them():
+    """Comm.from_torch_dist broadcasts the 128-byte RCCL id from rank 0.  If rank 0 cannot create it (no librccl), the other ranks must not be
+    left waiting in the broadcast: the failure travels in the broadcast's slot and every rank raises (bench.py then takes torch.distributed)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uid_fail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
