@@ -15,9 +15,17 @@
 // downstream (bias / LayerNorm gradients over 12 608 rows) add up linearly.  So every chain here is TWO chains: half of its steps run with one
 // operand negated into a second accumulator and the result is their difference -- the rounding directions cancel, and the two independent
 // chains also pipeline better.
-// One workgroup (8 waves) per (batch, head); forward: K and V tiles in LDS; backward: one launch, blocks [0, BH) hold K, V and produce dQ,
-// blocks [BH, 2 BH) hold Q, dO (+ lse, delta = rowsum(dO * O)) and produce dK, dV; no atomics.  P is recomputed from the forward's
-// log-sum-exp; nothing of size N x N goes to HBM.
+// One workgroup (8 waves) per (batch, head); forward: K and V tiles in LDS; backward: TWO launches: the dQ workgroups (K, V in LDS) first --
+// they also produce delta --, then the dK / dV workgroups (Q, dO in LDS, lse and delta from global); no atomics.  P is recomputed from the
+// forward's log-sum-exp; nothing of size N x N goes to HBM.
+// delta (round 6): the softmax backward is dS = P o (dP - delta) with delta_i = sum_j P_ij dP_ij.  The flash form delta_i = rowsum(dO_i o O_i) is
+// the same number in exact arithmetic, but in fp32 the two differ by the rounding of two differently-ordered, cancelling sums, and then
+// rowsum_j(dS_ij) is not ~0: the residual r_i enters dK as sum_i r_i Q_i -- a term that does not average out over the rows, so the column sums
+// downstream (norm1.bias = colsum(dqkv) . W) carry it: 1.0e-4 of the worst tensor of the 768-wide parity case against the fp32 oracle's 2.7e-5
+// (tools/fp32_colsum_probe.py: everything upstream of this kernel was 4x closer to exact than the oracle, its output 2x further).  So delta is
+// formed the way torch's softmax backward forms it: from the SAME P and dP the dS uses, delta_i = (sum_j P_ij dP_ij) / (sum_j P_ij) (a first pass of
+// the dQ workgroup over its keys; the dK / dV side recomputes bit-identical P and dP: the products commute and both sides visit the head
+// dimension in the same order).
 // LDS tiles are [rows][64] fp32 with 256-byte rows and the 16-byte chunk q of row r stored at chunk q ^ sig(r), sig(r) = (r & 3) | tau((r >> 2) & 3) << 2,
 // tau = (0, 3, 1, 2): conflict-free for BOTH read forms (row reads: 16 rows x one chunk; row-group reads: 4 rows x 16 chunks) under
 // ds_read_b128's lane grouping {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...
@@ -147,8 +155,8 @@ __global__ void __launch_bounds__(64 * AW) k_attn_f32_fwd(const float* __restric
 }
 
 // ======================================================================== backward
-__device__ __forceinline__ void attn_f32_dq_body(float* smf, int bh, const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ dout,
-                                                 const float* __restrict__ lse, float* __restrict__ dqkv, int N, int H, int nf, float scale) {
+__device__ __forceinline__ void attn_f32_dq_body(float* smf, int bh, const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                 const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, int N, int H, int nf, float scale) {
   const int NP = 16 * nf;
   float* Ks = smf;
   float* Vs = smf + NP * 64;
@@ -156,7 +164,6 @@ __device__ __forceinline__ void attn_f32_dq_body(float* smf, int bh, const float
   const int b = bh / H, h = bh % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const float* base = qkv + (size_t)b * N * D3 + h * 64;
-  const float* obase = o + (size_t)b * N * Dm + h * 64;
   const float* dobase = dout + (size_t)b * N * Dm + h * 64;
   stage_f32(Ks, base + Dm, D3, N, NP, tid);
   stage_f32(Vs, base + 2 * Dm, D3, N, NP, tid);
@@ -164,19 +171,32 @@ __device__ __forceinline__ void attn_f32_dq_body(float* smf, int bh, const float
   const int nqb = (N + 15) >> 4;
   for (int qb = wave; qb < nqb; qb += AW) {
     const int qrow = qb * 16 + c;
-    float4 qf[4], dof[4], of[4];
+    float4 qf[4], dof[4];
     row_frag_g(qf, base, D3, qrow, N, g);
     row_frag_g(dof, dobase, Dm, qrow, N, g);
-    row_frag_g(of, obase, Dm, qrow, N, g);
-    float dl = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dl += dof[j].x * of[j].x + dof[j].y * of[j].y + dof[j].z * of[j].z + dof[j].w * of[j].w;
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);                                      // delta[q = c]
     const float lq = qrow < N ? lse[((size_t)b * H + h) * N + qrow] : 1e30f;
     float4 nqf[4], ndof[4];
     neg_frag(nqf, qf);
     neg_frag(ndof, dof);
+    // pass 1: delta[q = c] = (sum_j P dP) / (sum_j P) over the keys (fixed order: v, key block, then the four lane groups).  The division matters:
+    // P = exp(S - lse) sums to 1 + eps (the fp32 log-sum-exp), and dP_ij = dO_i . V_j carries a component common to all j; with delta = sum P dP
+    // alone that component survives in dS as eps x common mode (measured: 4x WORSE than the flash form), divided by sum P it cancels exactly
+    // and rowsum_j(dS_ij) = sum P dP - delta sum P = 0 to the last bit of the two sums -- what torch's softmax backward gets from its normalised P.
+    float sd = 0.f, sp = 0.f;
+    for (int f = 0; f < nf; ++f) {
+      float4 kf[4], vf[4];
+      row_frag_l(kf, Ks, f * 16 + c, g);
+      row_frag_l(vf, Vs, f * 16 + c, g);
+      const f32x4 st = dot_hd(kf, qf, nqf);
+      const f32x4 dpt = dot_hd(vf, dof, ndof);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (16 * f + 4 * g + v < N) { const float pv = expf(st[v] * scale - lq); sp += pv; sd += pv * dpt[v]; }
+    }
+    sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
+    sp += __shfl_xor(sp, 16, 64); sp += __shfl_xor(sp, 32, 64);
+    const float dl = qrow < N ? sd / sp : 0.f;                          // delta[q = c]
+    if (g == 0 && qrow < N) delta[((size_t)b * H + h) * N + qrow] = dl;
     f32x4 dq[4], dqn[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dqn[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -197,8 +217,8 @@ __device__ __forceinline__ void attn_f32_dq_body(float* smf, int bh, const float
   }
 }
 
-__device__ __forceinline__ void attn_f32_dkv_body(float* smf, int bh, const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ dout,
-                                                  const float* __restrict__ lse, float* __restrict__ dqkv, int N, int H, int nf, float scale) {
+__device__ __forceinline__ void attn_f32_dkv_body(float* smf, int bh, const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                  const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv, int N, int H, int nf, float scale) {
   const int NP = 16 * nf;
   float* Qs = smf;
   float* Ds = smf + NP * 64;
@@ -208,23 +228,12 @@ __device__ __forceinline__ void attn_f32_dkv_body(float* smf, int bh, const floa
   const int b = bh / H, h = bh % H;
   const long D3 = 3L * H * 64, Dm = (long)H * 64;
   const float* base = qkv + (size_t)b * N * D3 + h * 64;
-  const float* obase = o + (size_t)b * N * Dm + h * 64;
   const float* dobase = dout + (size_t)b * N * Dm + h * 64;
   stage_f32(Qs, base, D3, N, NP, tid);
-  for (int idx = tid; idx < NP * 16; idx += 64 * AW) {      // dO tile + delta = rowsum(dO * O): a row's 16 chunks sit in 16 consecutive lanes
-    const int row = idx >> 4, q = idx & 15;
-    float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), ov = dv;
-    if (row < N) { dv = *(const float4*)(dobase + (size_t)row * Dm + q * 4); ov = *(const float4*)(obase + (size_t)row * Dm + q * 4); }
-    *(float4*)(Ds + row * 64 + ((q ^ sig(row)) << 2)) = dv;
-    float d = dv.x * ov.x + dv.y * ov.y + dv.z * ov.z + dv.w * ov.w;
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
-    d += __shfl_xor(d, 8, 64);
-    if (q == 0) {
-      del_s[row] = d;
-      lse_s[row] = row < N ? lse[((size_t)b * H + h) * N + row] : 1e30f;     // padded queries: P = exp(. - 1e30) = 0
-    }
+  stage_f32(Ds, dobase, Dm, N, NP, tid);
+  for (int row = tid; row < NP; row += 64 * AW) {            // lse and delta (the dQ launch wrote it) of every query; padded queries: P = exp(. - 1e30) = 0
+    lse_s[row] = row < N ? lse[((size_t)b * H + h) * N + row] : 1e30f;
+    del_s[row] = row < N ? delta[((size_t)b * H + h) * N + row] : 0.f;
   }
   __syncthreads();
   const int nkb = (N + 15) >> 4;
@@ -272,12 +281,12 @@ __device__ __forceinline__ void attn_f32_dkv_body(float* smf, int bh, const floa
   }
 }
 
-__global__ void __launch_bounds__(64 * AW) k_attn_f32_bwd(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ dout,
-                                                          const float* __restrict__ lse, float* __restrict__ dqkv, int B, int N, int H, int nf, float scale) {
+template <int PART>      // 0: the dQ workgroups (write delta), 1: the dK / dV workgroups (read it): two launches, in this order
+__global__ void __launch_bounds__(64 * AW) k_attn_f32_bwd(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, float* __restrict__ dqkv, int B, int N, int H, int nf, float scale) {
   extern __shared__ __attribute__((aligned(16))) float smf[];
-  const int half = B * H;
-  if ((int)blockIdx.x < half) attn_f32_dq_body(smf, blockIdx.x, qkv, o, dout, lse, dqkv, N, H, nf, scale);
-  else attn_f32_dkv_body(smf, blockIdx.x - half, qkv, o, dout, lse, dqkv, N, H, nf, scale);
+  if (PART == 0) attn_f32_dq_body(smf, blockIdx.x, qkv, dout, lse, delta, dqkv, N, H, nf, scale);
+  else attn_f32_dkv_body(smf, blockIdx.x, qkv, dout, lse, delta, dqkv, N, H, nf, scale);
 }
 
 // ======================================================================== launchers (1 = shape not covered: the caller takes the VALU kernels)
@@ -307,13 +316,20 @@ int fc_attn_f32_fwd(const float* qkv, float* o, float* lse, int B, int N, int H,
   }
   return 1;
 }
-int fc_attn_f32_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, int B, int N, int H, int d, float scale, hipStream_t s) {
+int fc_attn_f32_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* delta, float* dqkv, int B, int N, int H, int d, float scale,
+                    hipStream_t s) {
   static const int on = fc_knob("FC_ATTN_F32_MFMA", 1);
-  if (!on || !f32_ok(N, d, qkv, o, dout) || ((uintptr_t)dqkv & 15)) return 1;
+  (void)o;                                                  // (delta no longer comes from rowsum(dO o O): see the header)
+  if (!on || !delta || !f32_ok(N, d, qkv, dout, dqkv)) return 1;
   const int nf = f32_nf(N), lds = 2 * 16 * nf * 256 + 2 * 16 * nf * 4;
   static int lds_set = 0;
-  if (lds > lds_set) { FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_attn_f32_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); lds_set = lds; }
-  hipLaunchKernelGGL(k_attn_f32_bwd, dim3(2 * B * H), dim3(64 * AW), lds, s, qkv, o, dout, lse, dqkv, B, N, H, nf, scale);
+  if (lds > lds_set) {
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_attn_f32_bwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    FC_CHECK_HIP(hipFuncSetAttribute((const void*)k_attn_f32_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(k_attn_f32_bwd<0>, dim3(B * H), dim3(64 * AW), lds, s, qkv, dout, lse, delta, dqkv, B, N, H, nf, scale);
+  hipLaunchKernelGGL(k_attn_f32_bwd<1>, dim3(B * H), dim3(64 * AW), lds, s, qkv, dout, lse, delta, dqkv, B, N, H, nf, scale);
   FC_LAUNCH_CHECK();
   return 0;
 }

@@ -162,7 +162,8 @@ int fc_gemm_mfma(int kind, int dtC, const bf16_t* A, long lda, const bf16_t* Bm,
 int fc_gemm_x3(int kind, const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K, const GemmEpi& epi, hipStream_t s);
 // ---- fp32 attention as v_mfma_f32_16x16x4_f32 chains (fc_attn_f32.hip): head_dim 64, N <= 224; 1 = shape not covered
 int fc_attn_f32_fwd(const float* qkv, float* o, float* lse, int B, int N, int H, int d, float scale, hipStream_t s);
-int fc_attn_f32_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, int B, int N, int H, int d, float scale, hipStream_t s);
+int fc_attn_f32_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* delta /* [B, H, N] scratch */, float* dqkv, int B, int N, int H, int d,
+                    float scale, hipStream_t s);
 // the fp32 mode's weight gradients: dW[out,in] = dY[rows,out]^T . X[rows,in] (stored) and db += column sums of dY, reduction cut into slices
 int fc_dw_x3(const float* dY, const float* X, float* dW, float* db, int rows, int out, int in, hipStream_t s);
 // the same kernel over one or two problems that share N, K and the epilogue kind (image + text tower of a layer in one launch);

@@ -653,7 +653,7 @@ struct Ctx {
       int r = fc_attn_bwd_mfma((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dO, lse, delta, (bf16_t*)dqkv, B, N, H, d, scale, s);
       if (r <= 0) return r;
     } else if (dt == FC_F32) {
-      int r = fc_attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)dO, lse, (float*)dqkv, B, N, H, d, scale, s);
+      int r = fc_attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)dO, lse, delta, (float*)dqkv, B, N, H, d, scale, s);
       if (r <= 0) return r;
     }
     return fc_attn_bwd_generic(dt, qkv, o, dO, lse, delta, dqkv, B, N, H, d, scale, s);
@@ -2443,7 +2443,7 @@ extern "C" int fc_k_attention_bwd(int32_t impl, int32_t dt, const void* qkv, con
                                   void* dqkv, int32_t B, int32_t N, int32_t H, int32_t d, float scale, void* stream) {
   if (impl == 1) {
     if (dt == FC_F32)
-      return fc_attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)dout, lse, (float*)dqkv, B, N, H, d, scale, (hipStream_t)stream);
+      return fc_attn_f32_bwd((const float*)qkv, (const float*)o, (const float*)dout, lse, delta, (float*)dqkv, B, N, H, d, scale, (hipStream_t)stream);
     FC_REQUIRE(dt == FC_BF16, "MFMA attention takes bf16 or fp32");
     return fc_attn_bwd_mfma((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, B, N, H, d, scale,
                             (hipStream_t)stream);
