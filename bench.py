@@ -578,18 +578,37 @@ def launch_command(gpus, argv, port, python=None, script=None):
     return cmd, {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
 
 
-def negotiate_comm(dist, make_comm, flag_device, skip=False):
+COMM_STUCK = [False]      # a communicator creation that never returned is still running in a daemon thread: main() leaves through os._exit
+
+
+def negotiate_comm(dist, make_comm, flag_device, skip=False, timeout_s=None):
     """The C-ABI RCCL communicator for the timed aggregation, or a recorded reason why not -- decided TOGETHER: if any rank fails to create
     it, every rank closes its own and the run continues on torch.distributed's all-reduce (RCCL as well) with `cabi_comm_error` in the line.
-    Returns (comm or None, error string or None).  make_comm() -> object with .close(); it may raise."""
+    Returns (comm or None, error string or None).  make_comm() -> object with .close(); it may raise -- or never return: the creation
+    (ncclCommInitRank, a collective nobody has run with more than one rank on this pool) runs in a daemon thread that is given `timeout_s`
+    (FC_BENCH_COMM_TIMEOUT, default 120 s); a rank whose thread is still running then counts as failed like any other."""
+    import threading
     import torch
     if skip:
         return None, None
-    comm, err = None, None
-    try:
-        comm = make_comm()
-    except Exception as e:                                         # keep the run: the torch.distributed path is RCCL as well
-        err = f"{type(e).__name__}: {e}"[:300]
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("FC_BENCH_COMM_TIMEOUT", "120"))
+    box = {}
+
+    def work():
+        try:
+            if torch.device(flag_device).type == "cuda":           # HIP's current device is per thread: this rank's GPU, not device 0
+                torch.cuda.set_device(flag_device)
+            box["comm"] = make_comm()
+        except Exception as e:                                     # keep the run: the torch.distributed path is RCCL as well
+            box["err"] = f"{type(e).__name__}: {e}"[:300]
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    comm, err = box.get("comm"), box.get("err")
+    if th.is_alive():
+        COMM_STUCK[0] = True
+        comm, err = None, f"creating the C-ABI communicator did not return within {timeout_s:g} s (still running in a daemon thread)"
     ok = torch.tensor([0 if comm is None else 1], device=flag_device)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)                      # every rank takes the same path
     if int(ok) == 0 and comm is not None:
@@ -995,6 +1014,10 @@ def main():
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out), file=line_out, flush=True)
     if world > 1:
+        if COMM_STUCK[0]:      # a native call that never returned holds this process's RCCL state: no orderly teardown, the line is out
+            line_out.flush()
+            sys.stderr.flush()
+            os._exit(0)
         if comm_c is not None:
             comm_c.close()
         dist.destroy_process_group()

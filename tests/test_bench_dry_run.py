@@ -105,10 +105,15 @@ def _negotiate_worker(rank, world, port, fail_rank, q):
                 closed.append(rank)
 
         def make():
+            if fail_rank == "hang":                      # a collective that never completes: every rank sits in it
+                import time
+                time.sleep(3600)
             if rank == fail_rank or fail_rank == "all":
                 raise RuntimeError("librccl.so could not be loaded")
             return FakeComm()
-        comm, err = b.negotiate_comm(dist, make, "cpu")
+        comm, err = b.negotiate_comm(dist, make, "cpu", timeout_s=(1.0 if fail_rank == "hang" else 60.0))
+        if fail_rank == "hang":
+            assert b.COMM_STUCK[0] is True
         q.put((rank, comm is None, err, closed, b.aggregate_path_name(world, comm, dist.get_backend())))
     except Exception:  # noqa: BLE001
         import traceback
@@ -117,10 +122,11 @@ def _negotiate_worker(rank, world, port, fail_rank, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fail_rank", [1, "all", None])
+@pytest.mark.parametrize("fail_rank", [1, "all", None, "hang"])
 def test_a_failed_cabi_communicator_on_any_rank_moves_every_rank_to_torch_distributed(fail_rank):
-    """bench.py at N > 1: if Comm.from_torch_dist() fails on ANY rank, every rank must give up its own C-ABI communicator and the line
-    must still be produced on the torch.distributed path with the reason recorded (cabi_comm_error); two gloo ranks on the CPU."""
+    """bench.py at N > 1: if Comm.from_torch_dist() fails on ANY rank -- or never returns ("hang": the creation runs in a daemon thread with a
+    time limit) -- every rank must give up its own C-ABI communicator and the line must still be produced on the torch.distributed path with
+    the reason recorded (cabi_comm_error); two gloo ranks on the CPU."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -140,3 +146,5 @@ def test_a_failed_cabi_communicator_on_any_rank_moves_every_rank_to_torch_distri
             assert none is True and err and path == "HIP blend + torch.distributed.all_reduce (gloo)"
             if fail_rank == 1:
                 assert closed == ([0] if rank == 0 else []) and (("librccl" in err) if rank == 1 else ("another rank" in err))
+            if fail_rank == "hang":
+                assert "did not return within" in err and closed == []
