@@ -62,6 +62,7 @@ SIGNATURES = {
     "fc_contrastive_scratch_floats": (_Z, [_I]),
     "fc_ce_loss_fwd_bwd": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     "fc_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
+    "fc_sgd_step": (C.c_int, [_P, _P, _P, _P, _F, _F, _I, _F, _I, _P]),
     "fc_client_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _I, _P, _P, _Z, _P]),
     "fc_model_side_stream": (C.c_void_p, [_P]),
     "fc_gather_rows": (C.c_int, [_P, _P, _I, _I, _P, _P]),

@@ -71,6 +71,8 @@ class CreamflClient(FedavgClient):
 
     # ------------------------------------------------------------------ hooks of FedavgClient.update
     def _before_update(self, st):
+        if self.args.optimizer != "AdamW":
+            raise NotImplementedError("CreamflClient is implemented on the fused HIP path (AdamW, no max_grad_norm on the local epochs)")
         model = self.model
         self.old_model = copy.deepcopy(model)                 # creamflclient.py:74 (device-to-device clone of the flat buffer)
         self.old_model.eval()

@@ -100,8 +100,9 @@ class FedavgClient(BaseClient):
         model.to(self.device)
         prox = self._prox()
         oargs = self._refine_optim_args(self.args)
-        fused = self.args.optimizer == "AdamW" and not getattr(self.args, "distributed", False) and \
+        fused = self.args.optimizer in ("AdamW", "SGD") and not getattr(self.args, "distributed", False) and \
             not getattr(self.args, "mm_distributed", False) and not getattr(self.args, "force_unfused", False)
+        sgd = self.args.optimizer == "SGD"       # main.py:269: the argument's default; composed on the device like the clipped AdamW step
         if not fused:
             return self._update_unfused(mm, oargs, prox)
         dev = model.flat.device
@@ -120,9 +121,15 @@ class FedavgClient(BaseClient):
         exp_avg_sq = torch.zeros(n, device=dev)
         lossbuf = torch.zeros(2, device=dev)
         lr = float(oargs.get("lr", 1e-3))
+        if sgd:
+            momentum, nesterov = float(oargs.get("momentum", 0.0)), bool(oargs.get("nesterov", False))
+            if nesterov and (momentum <= 0 or float(oargs.get("dampening", 0.0)) != 0):
+                raise ValueError("Nesterov momentum requires a momentum and zero dampening")      # torch.optim.SGD's own check
+            if float(oargs.get("dampening", 0.0)) != 0 or oargs.get("maximize", False):
+                return self._update_unfused(mm, oargs, prox)
         betas = oargs.get("betas", (0.9, 0.999))
         eps = float(oargs.get("eps", 1e-8))
-        wd = float(oargs.get("weight_decay", 1e-2))
+        wd = float(oargs.get("weight_decay", 0.0 if sgd else 1e-2))      # torch's defaults: SGD 0, AdamW 1e-2
         L = _lib.lib()
         if prox is not None:
             prox_scratch = torch.empty(L.fc_prox_scratch_bytes(model._handle.h), dtype=torch.uint8, device=dev)
@@ -179,15 +186,20 @@ class FedavgClient(BaseClient):
                     self._collect_metrics(mm, ws, B, labels)
                     num += 1
                     continue
-                if max_norm > 0:
+                if max_norm > 0 or sgd:
                     self._forward_backward(st, img, ids, labels, B, n_txt, dp, ws, lossbuf)
                     if prox is not None:
                         check(L.fc_prox_term(model._handle.h, ptr(model.flat), ptr(prox[0]), float(prox[1]), B, ptr(grads), ptr(lossbuf),
                                              ptr(prox_scratch), prox_scratch.numel(), _lib.stream_ptr()))
-                    check(L.fc_clip_grad_norm(model._handle.h, ptr(grads), max_norm, ptr(clip_scratch), clip_scratch.numel(), None,
-                                              _lib.stream_ptr()))
-                    check(L.fc_adamw_step(model._handle.h, ptr(model.flat), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), lr, float(betas[0]),
-                                          float(betas[1]), eps, wd, step, _lib.stream_ptr()))
+                    if max_norm > 0:
+                        check(L.fc_clip_grad_norm(model._handle.h, ptr(grads), max_norm, ptr(clip_scratch), clip_scratch.numel(), None,
+                                                  _lib.stream_ptr()))
+                    if sgd:                                            # exp_avg doubles as the momentum buffer (fresh every round, like the optimizer)
+                        check(L.fc_sgd_step(model._handle.h, ptr(model.flat), ptr(grads), ptr(exp_avg), lr, momentum, int(nesterov), wd, step,
+                                            _lib.stream_ptr()))
+                    else:
+                        check(L.fc_adamw_step(model._handle.h, ptr(model.flat), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), lr, float(betas[0]),
+                                              float(betas[1]), eps, wd, step, _lib.stream_ptr()))
                     model._bump()                                      # the compute weights are rebuilt by the next prepare_weights()
                     st["steps_done"] = step
                     self._count_step(st, None)

@@ -893,6 +893,43 @@ int fc_adamw(float* p, float* g, float* m, float* v, size_t n, float lr, float b
   return 0;
 }
 
+// ---- torch.optim.SGD.step (fedavgclient.py:63 with --optimizer SGD: lr, momentum, weight_decay, nesterov from args; dampening 0)
+//   g' = g + wd p ; buf = first ? g' : momentum buf + g' ; d = nesterov ? g' + momentum buf : buf (momentum == 0: d = g') ; p -= lr d
+__global__ void __launch_bounds__(256) k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n, float lr, float momentum,
+                                             int nesterov, float wd, int first, bf16_t* __restrict__ shadow) {
+#pragma clang fp contract(off)      // torch rounds every product and sum on its own (add_(alpha) aside: one multiply, one add)
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 pp = ((float4*)p)[i], gg = ((const float4*)g)[i], bb = momentum != 0.f && !first ? ((float4*)buf)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* P = (float*)&pp; float* G = (float*)&gg; float* Bf = (float*)&bb;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float d = G[k];
+      if (wd != 0.f) d = d + wd * P[k];
+      if (momentum != 0.f) {
+        Bf[k] = first ? d : momentum * Bf[k] + d;
+        d = nesterov ? d + momentum * Bf[k] : Bf[k];
+      }
+      P[k] = P[k] - lr * d;
+    }
+    ((float4*)p)[i] = pp;
+    if (momentum != 0.f) ((float4*)buf)[i] = bb;
+    if (shadow) {
+      ushort4 sh; sh.x = f2bf(P[0]); sh.y = f2bf(P[1]); sh.z = f2bf(P[2]); sh.w = f2bf(P[3]);
+      ((ushort4*)shadow)[i] = sh;
+    }
+  }
+}
+int fc_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, int nesterov, float wd, int first, void* shadow_bf16, hipStream_t s) {
+  FC_REQUIRE(n % 4 == 0 && ((uintptr_t)p % 16 == 0), "sgd: buffer must be 16B aligned and a multiple of 4 elements");
+  const size_t n4 = n / 4;
+  int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_sgd, dim3(grid), dim3(256), 0, s, p, g, buf, n, lr, momentum, nesterov, wd, first, (bf16_t*)shadow_bf16);
+  FC_LAUNCH_CHECK();
+  return 0;
+}
+
 FcAdamW fc_adamw_consts(float lr, float beta1, float beta2, float eps, float wd, int step) {
   FcAdamW o;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);

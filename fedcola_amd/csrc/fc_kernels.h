@@ -84,6 +84,8 @@ int fc_ce_fwd_bwd(const float* logits, const int64_t* y, int B, int C, float* lo
 // ---- optimizer (K13): torch.optim.AdamW semantics; optionally refreshes the low-precision shadow and zeroes grads
 int fc_adamw(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd,
              int step, void* shadow_bf16, int zero_grad, hipStream_t s);
+// torch.optim.SGD.step over a flat range (momentum buffer `buf`; first = the parameters' first step: buf = g + wd p); shadow: bf16 copy of p or null
+int fc_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, int nesterov, float wd, int first, void* shadow_bf16, hipStream_t s);
 // AdamW constants of one optimizer step + the flat buffers they apply to (same element offsets in all of them).  Used by the
 // stand-alone kernels and by the weight-gradient GEMM's fused epilogue (fc_gemm_tn_grouped with `opt`): one formula, one rounding
 // sequence (fc_adamw_elem), so the fused and the separate optimizer produce the same bits from the same gradient.

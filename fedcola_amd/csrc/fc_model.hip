@@ -1957,6 +1957,25 @@ extern "C" int fc_adamw_step(const fc_model_t* m, float* params, float* grads, f
   return adamw_ranges(m, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
+// torch.optim.SGD.step over the trainable ranges of the flat buffers (frozen segments skipped like torch skips grad-less parameters)
+extern "C" int fc_sgd_step(const fc_model_t* m, float* params, const float* grads, float* momentum_buf, float lr, float momentum, int32_t nesterov,
+                           float weight_decay, int32_t step, void* stream) {
+  FC_REQUIRE(step >= 1, "sgd: step is 1-based");
+  FC_REQUIRE(momentum == 0.f || momentum_buf, "sgd: momentum needs a buffer");
+  FC_REQUIRE(!nesterov || momentum > 0.f, "Nesterov momentum requires a momentum and zero dampening");      // torch's own check
+  size_t i = 0, n = m->segs.size();
+  while (i < n) {
+    if (!m->segs[i].trainable) { ++i; continue; }
+    size_t j = i;
+    while (j + 1 < n && m->segs[j + 1].trainable) ++j;
+    const int64_t beg = m->segs[i].offset, end = (j + 1 < n) ? m->segs[j + 1].offset : m->total;
+    FC_TRY(fc_sgd(params + beg, grads + beg, momentum_buf ? momentum_buf + beg : nullptr, (size_t)(end - beg), lr, momentum, nesterov, weight_decay, step == 1,
+                  nullptr, (hipStream_t)stream));
+    i = j + 1;
+  }
+  return 0;
+}
+
 // exp(clamp(log(1/0.07), 0, log 100)) evaluated in fp32 like the upstream nn.Parameter (a fresh criterion is built
 // every step at fedavgclient.py:95, so the temperature never trains)
 static float contrastive_tau() { return expf(fminf(fmaxf(logf(1.0f / 0.07f), 0.0f), logf(100.0f))); }

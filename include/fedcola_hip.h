@@ -30,7 +30,7 @@ extern "C" {
 #define FC_ABI_VERSION 6   /* 2: fc_comm_*, fc_aggregate*, fc_workspace_tensor, fc_k_layernorm_bwd_partial; 3: fc_model_cfg.colearn_attn, fc_k_dw;
                               4: fc_image_u8_to_f32, fc_k_gemm_epi; fc_k_layernorm_partial_floats counts fp64 rows;
                               5: fc_k_mlp_pack, fc_k_mlp_fused, fc_model_set_option;
-                              6: those three left the product library: they exist in the tools build only (#ifdef FC_PROBES below) */
+                              6: those three left the product library: they exist in the tools build only (#ifdef FC_PROBES below); + fc_sgd_step */
 
 enum { FC_PREC_FP32 = 0, FC_PREC_BF16 = 1 };
 enum { FC_TASK_NONE = 0, FC_TASK_CLS = 1, FC_TASK_RTV = 2 };
@@ -112,6 +112,12 @@ int fc_ce_loss_fwd_bwd(const float* logits, const int64_t* y, int32_t B, int32_t
 /* ---- torch.optim.AdamW.step over the trainable ranges of the flat buffers (fedavgclient.py:63,100). step is 1-based. */
 int fc_adamw_step(const fc_model_t* m, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* ---- torch.optim.SGD.step (fedavgclient.py:63 with --optimizer SGD, main.py:269-273: lr, momentum, nesterov, weight_decay from args; dampening 0)
+ * over the trainable ranges: g' = g + wd p; buf = (step == 1) ? g' : momentum buf + g'; p -= lr (nesterov ? g' + momentum buf : buf)
+ * (momentum == 0: p -= lr g', momentum_buf may be NULL).  The caller re-runs fc_prepare_weights before the next forward.  step is 1-based. */
+int fc_sgd_step(const fc_model_t* m, float* params, const float* grads, float* momentum_buf, float lr, float momentum, int32_t nesterov,
+                float weight_decay, int32_t step, void* stream);
 
 /* ---- one iteration of FedavgClient.update's batch loop (fedavgclient.py:79-102), fully on device:
  * zero_grad -> forward -> criterion -> backward -> AdamW.step -> refresh compute weights.

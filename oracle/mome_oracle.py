@@ -447,6 +447,22 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
+def sgd_step(p: Tensor, g: Tensor, buf, lr: float, momentum: float = 0.0, nesterov: bool = False, weight_decay: float = 0.0,
+             dampening: float = 0.0):
+    """One torch.optim.SGD step, in place on p; returns the momentum buffer (None in: the parameter's first step -> buf = clone(g)).
+    The reference builds it through _refine_optim_args (fedavgclient.py:34-42, 63): lr, momentum, nesterov, weight_decay from args."""
+    if weight_decay != 0.0:
+        g = g.add(p, alpha=weight_decay)
+    if momentum != 0.0:
+        if buf is None:
+            buf = g.clone()
+        else:
+            buf.mul_(momentum).add_(g, alpha=1.0 - dampening)
+        g = g.add(buf, alpha=momentum) if nesterov else buf
+    p.add_(g, alpha=-lr)
+    return buf
+
+
 # --------------------------------------------------------------------------- whole client step
 def trainable_keys(p: Dict[str, Tensor], cfg: OracleCfg) -> List[str]:
     """Keys of nn.Parameters with requires_grad (aux_weight only when aux_trained; buffers excluded)."""
@@ -474,9 +490,10 @@ def prox_term(p: Dict[str, Tensor], g: Dict[str, Tensor], mu: float, keys: Seque
     return mu * (0.5 * total), grads
 
 
-def client_step(p, cfg: OracleCfg, batch, state, lr: float, weight_decay: float = 0.0, dp_masks=None, prox=None):
+def client_step(p, cfg: OracleCfg, batch, state, lr: float, weight_decay: float = 0.0, dp_masks=None, prox=None, sgd=None):
     """One iteration of FedavgClient.update's batch loop (fedavgclient.py:79-102):
-    zero_grad -> fwd -> loss -> bwd -> AdamW.step.  ``state`` = {'step': int, 'm': {k}, 'v': {k}}.
+    zero_grad -> fwd -> loss -> bwd -> AdamW.step (sgd = (momentum, nesterov): torch.optim.SGD.step instead, buffers in state['m']).
+    ``state`` = {'step': int, 'm': {k}, 'v': {k}}.
     batch: ('img+txt', img, ids) | ('img', img, y) | ('txt', ids, y).  Returns (loss, outs, grads).
     prox = (global_params, mu): FedproxClient.update (fedproxclient.py:64-67) -- the proximal term joins loss and grads."""
     kind = batch[0]
@@ -505,6 +522,9 @@ def client_step(p, cfg: OracleCfg, batch, state, lr: float, weight_decay: float 
     state["step"] += 1
     for k in trainable_keys(p, cfg):
         if k not in grads:          # parameter without grad: torch optimizers skip it
+            continue
+        if sgd is not None:
+            state["m"][k] = sgd_step(p[k], grads[k], state["m"].get(k), lr, momentum=sgd[0], nesterov=sgd[1], weight_decay=weight_decay)
             continue
         if k not in state["m"]:
             state["m"][k] = torch.zeros_like(p[k])

@@ -9,6 +9,7 @@ Outputs (tests/golden/):
     update_toy.json     FedavgClient.update() result dict + final weights fingerprint
     update_prox_toy.json  the same for FedproxClient.update() (mu = 0.5)
     update_clip_toy.json  the same for FedavgClient.update() with max_grad_norm = 1.0
+    update_sgd_toy.json   the same with --optimizer SGD --momentum 0.9 --nesterov --weight_decay 1e-3
     server_update.json    three rounds of FedavgServer.update(): warm-up filter, freeze / unfreeze, aux refresh, LR decay
     agg.json            FedavgServer._aggregate outputs over the scope / compensation matrix
     agg_colearn.json    the same with colearn_param='attn' img+txt models (shared Attention tensors listed under both towers' keys)
@@ -199,6 +200,25 @@ def update_clip_case():
     with open(os.path.join(HERE, "update_clip_toy.json"), "w") as f:
         json.dump(rec, f)
     print("update clip", res, "first-batch grad norm", norm0)
+
+
+def update_sgd_case():
+    """FedavgClient.update() with --optimizer SGD --momentum 0.9 --nesterov (main.py:269-273: SGD is the argument's default; _refine_optim_args,
+    fedavgclient.py:34-42, hands torch.optim.SGD lr / momentum / weight_decay / nesterov from args)."""
+    c = CASES["toy"]
+    args = RefArgs(E=2, B=4, lr=1e-2, optimizer="SGD", no_shuffle=True, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    ds = SynthPairs(10, 8, 30)
+    cl = ref.fedavgclient.FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt",
+                                       eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cpu"
+    cl.download({"Flickr30k": build(c["mk"])})
+    res = cl.update()
+    sd = cl.upload()
+    rec = dict(results={str(k): v for k, v in res.items()}, n=10, B=4, E=2, lr=1e-2, momentum=0.9, nesterov=True, weight_decay=1e-3,
+               after={k: pack(v, True) for k, v in sd.items() if v.dtype.is_floating_point})
+    with open(os.path.join(HERE, "update_sgd_toy.json"), "w") as f:
+        json.dump(rec, f)
+    print("update sgd", res)
 
 
 def server_update_case():
@@ -549,6 +569,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "server_update":
         server_update_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sgd":
+        update_sgd_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "clip":
         update_clip_case()
         sys.exit(0)
@@ -560,6 +583,7 @@ if __name__ == "__main__":
     update_case()
     update_prox_case()
     update_clip_case()
+    update_sgd_case()
     server_update_case()
     agg_case()
     agg_case("attn")

@@ -97,6 +97,66 @@ def test_client_update_with_gradient_clipping_matches_the_reference(path):
     assert abs(res[2]["loss"] - plain["results"]["2"]["loss"]) > 5e-3
 
 
+@pytest.mark.parametrize("path", ["composed", "torch"])
+def test_client_update_with_sgd_matches_the_reference(path):
+    """--optimizer SGD (main.py:269: the argument's default) with momentum 0.9, Nesterov, weight decay 1e-3: the device path composes the step
+    from fc_forward / criterion / fc_backward / fc_sgd_step; golden from the reference's update().  SGD is linear in the gradient (no Adam
+    sign sensitivity), so the weights are held tightly."""
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    rec = G.load("update_sgd_toy.json")
+    args = RefArgs(E=rec["E"], B=rec["B"], lr=rec["lr"], optimizer="SGD", no_shuffle=True, momentum=rec["momentum"], nesterov=rec["nesterov"],
+                   weight_decay=rec["weight_decay"], force_unfused=(path == "torch"))
+    ds = SynthPairs(rec["n"], 8, 30)
+    cl = FedavgClient(args=args, training_set=ds, test_set=ds, task="rtv", modality="img+txt", eval_metrics=[], criterion="ContrastiveLoss")
+    cl.id, cl.dataset, cl.device = 0, "Flickr30k", "cuda"
+    cl.download({"Flickr30k": toy_model()})
+    if path == "composed":
+        cl._update_unfused = None
+    res = cl.update()
+    for e in (1, 2):
+        assert abs(res[e]["loss"] - rec["results"][str(e)]["loss"]) <= 3e-4, (e, res[e], rec["results"][str(e)])
+    sd = cl.upload()
+    for k, r in rec["after"].items():
+        exp = torch.tensor(r["full"]).reshape(r["shape"])
+        assert float((sd[k].cpu() - exp).abs().max()) <= 5e-5 * max(1.0, float(exp.abs().max())), k
+
+
+def test_sgd_kernel_is_torch_sgd_to_the_last_ulps():
+    """fc_sgd_step over a model's trainable ranges against torch.optim.SGD on the same flat tensors: three steps (the first initialises the
+    buffer with the decayed gradient), Nesterov and plain momentum, a frozen segment left untouched.  Held to a few ulps, not bits: torch's
+    device kernels contract a + alpha b into one fused multiply-add, the library rounds the product and the sum separately (as torch's CPU
+    loop -- the reference's path -- does)."""
+    from fedcola_amd import _lib
+    m = toy_model()
+    L, P = _lib.lib(), _lib.ptr
+    frozen = list(m.segments)[4]
+    m.set_trainable(frozen, False)
+    for nesterov in (True, False):
+        torch.manual_seed(3)
+        p0 = torch.randn_like(m.flat.data)
+        flat = p0.clone(); buf = torch.zeros_like(flat)
+        ref_params = []
+        for k, sg in m.segments.items():
+            if k == frozen:
+                continue
+            t = p0[sg["offset"]: sg["offset"] + sg["numel"]].clone().requires_grad_(True)
+            ref_params.append((k, sg, t))
+        opt = torch.optim.SGD([t for _, _, t in ref_params], lr=0.05, momentum=0.9, nesterov=nesterov, weight_decay=0.01)
+        for step in (1, 2, 3):
+            g = torch.randn_like(flat) * 0.1
+            for _, sg, t in ref_params:
+                t.grad = g[sg["offset"]: sg["offset"] + sg["numel"]].clone()
+            opt.step()
+            _lib.check(L.fc_sgd_step(m._handle.h, P(flat), P(g), P(buf), 0.05, 0.9, int(nesterov), 0.01, step, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+        for k, sg, t in ref_params:
+            got = flat[sg["offset"]: sg["offset"] + sg["numel"]]
+            assert float((got - t.detach()).abs().max()) <= 4e-7 * max(1.0, float(t.detach().abs().max())), (nesterov, k)
+        sf = m.segments[frozen]
+        assert torch.equal(flat[sf["offset"]: sf["offset"] + sf["numel"]], p0[sf["offset"]: sf["offset"] + sf["numel"]])
+    m.set_trainable(frozen, True)
+
+
 def _round_server(device="cuda"):
     """A FedavgServer shell set up like tests/golden/make_golden.py::server_update_case builds the reference's."""
     import random

@@ -137,6 +137,31 @@ def test_update_result_schema_oracle_vs_golden():
         assert rec["results"][str(e + 1)]["metrics"] == {}
 
 
+def test_sgd_update_oracle_vs_golden():
+    """--optimizer SGD --momentum 0.9 --nesterov --weight_decay 1e-3 (main.py:269-273): the oracle's torch.optim.SGD restatement in the client loop
+    against the reference's FedavgClient.update() (update_sgd_toy.json): epoch losses and every weight."""
+    from oracle import mome_oracle as O
+    from synth import det_ids, det_tensor
+    from test_oracle_golden import cfg_from_mk
+    rec = G.load("update_sgd_toy.json")
+    cfg = cfg_from_mk(G.load("model_toy.json")["mk"])
+    p = G.case_weights("toy")
+    img = det_tensor((rec["n"], 3, 224, 224), 2000, 0.5)
+    ids = det_ids((rec["n"], 8), 11, 30)
+    state = dict(step=0, m={}, v={})
+    for e in range(rec["E"]):
+        tot = 0.0
+        for b0 in range(0, rec["n"], rec["B"]):
+            sl = slice(b0, min(rec["n"], b0 + rec["B"]))
+            loss, _, _ = O.client_step(p, cfg, ("img+txt", img[sl], ids[sl]), state, lr=rec["lr"], weight_decay=rec["weight_decay"],
+                                       sgd=(rec["momentum"], rec["nesterov"]))
+            tot += float(loss) * (sl.stop - sl.start)
+        assert abs(tot / rec["n"] - rec["results"][str(e + 1)]["loss"]) <= 2e-4
+    for k, r in rec["after"].items():
+        exp = torch.tensor(r["full"]).reshape(r["shape"])
+        assert float((p[k] - exp).abs().max()) <= 2e-5 * max(1.0, float(exp.abs().max())), k      # SGD is linear in the gradient: no Adam sign sensitivity
+
+
 def test_fedprox_update_oracle_vs_golden():
     """N3: the oracle loop with the proximal term (un-squared per-tensor norms) reproduces FedproxClient.update()'s result dict
     and the post-update weights of the reference (tests/golden/update_prox_toy.json)."""
