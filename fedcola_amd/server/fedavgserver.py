@@ -328,6 +328,19 @@ class FedavgServer(BaseServer):
         selected_ids = self._sample_clients()
         updated_sizes = self._request(selected_ids, eval=False, participated=True, retain_model=True, save_raw=False)
         _, rank, world = _dist()
+        if getattr(self.args, "fedavg_eval", False):                          # fedavgserver.py:796-808: what plain FedAvg would have produced, evaluated
+            import copy                                                       # centrally, then thrown away -- the round continues from the old models
+            old_models = copy.deepcopy(self.global_models)
+            for i, dataset in enumerate(self.global_models.keys()):
+                self.global_model = self.global_models[dataset]
+                self.task = DATASET_2_TASK[dataset]
+                self.modality = DATASET_2_MODALITY[dataset]
+                self.dataset = dataset
+                self.out_modality_scale = self.args.out_modality_scales[i]
+                self._aggregate(selected_ids, updated_sizes, fedavg=True)
+                self.global_models[dataset] = self.global_model
+            self._central_evaluate(fedavg=True)
+            self.global_models = old_models
         items = []
         for i, dataset in enumerate(self.global_models.keys()):
             self.global_model = self.global_models[dataset]

@@ -274,6 +274,21 @@ def server_update_case():
                                   models={ds: {k: pack(v, True) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
                                           for ds, m in srv.global_models.items()}))
         print("server round", r, ids, srv.curr_lr, {k: sum(v["requires_grad"].values()) for k, v in trace.items()})
+    # a fourth round with --fedavg_eval (fedavgserver.py:796-808): the models handed to _central_evaluate(fedavg=True) are what plain FedAvg would give;
+    # the round then continues from the old models
+    args.fedavg_eval = True
+    seen = {}
+    srv._central_evaluate = lambda fedavg=False: seen.update(
+        fedavg=bool(fedavg), models={ds: {k: pack(v, True) for k, v in m.state_dict().items() if v.dtype.is_floating_point} for ds, m in srv.global_models.items()})
+    srv._round = F.ROUND_N + 1
+    trace.clear()
+    ids = srv.update()
+    assert seen["fedavg"] is True
+    rec["fedavg_eval_round"] = dict(round=F.ROUND_N + 1, ids=[int(i) for i in ids], curr_lr=float(srv.curr_lr), evaluated=seen["models"],
+                                    models={ds: {k: pack(v, True) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+                                            for ds, m in srv.global_models.items()})
+    args.fedavg_eval = False
+    print("server round", F.ROUND_N + 1, "(fedavg_eval)", ids)
     # the three behaviours the fixture exists for must actually occur in it
     r1, r2, r3 = rec["rounds"]
     assert all(F.ROUND_DS[F.ROUND_LAYOUT[i][1]][1] == "txt" for i in r1["ids"])                                   # warm-up filter

@@ -97,6 +97,65 @@ def test_client_update_with_gradient_clipping_matches_the_reference(path):
     assert abs(res[2]["loss"] - plain["results"]["2"]["loss"]) > 5e-3
 
 
+def test_fedavg_eval_branch_evaluates_the_plain_fedavg_models_and_restores_the_old_ones():
+    """fedavgserver.py:796-808 (--fedavg_eval): before the real aggregation the round forms what plain FedAvg would give (fedavg=True: strict
+    dataset equality, no compensation), evaluates THOSE models centrally and restores the old ones.  Two servers from the same state and seed:
+    the one with fedavg_eval must (a) hand _central_evaluate models that equal the oracle's fedavg=True blend of the clients' uploads and differ
+    from the round's result, (b) end the round with exactly the models of the one without."""
+    import random
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    from fedcola_amd.server.fedavgserver import DATASET_2_MODALITY, DATASET_2_TASK
+    finals, seen = {}, {}
+    for flag in (False, True):
+        FedavgClient._POOL.clear()
+        srv, F = _round_server()
+        srv.args.fedavg_eval = flag
+        srv.args.warmup_modality = "none"                 # every modality trains in round 1: the two aggregations differ
+        srv.server_dataset = {}
+
+        def central(fedavg=False, srv=srv):
+            assert fedavg is True
+            seen["models"] = {ds: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for ds, m in srv.global_models.items()}
+        srv._central_evaluate = central
+        uploads = {}
+        orig_agg = type(srv)._aggregate
+
+        def spy_agg(ids, sizes, fedavg=False, srv=srv, **kw):
+            if fedavg and not uploads:                        # the clients' uploads as the first aggregation sees them
+                for i in ids:
+                    c = srv.clients[i]
+                    sd = {k: v.detach().cpu().clone() for k, v in c.model.state_dict().items()}
+                    uploads[i] = AO.upload_fold(sd, ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")) if c.modality != "img+txt" else sd
+                seen["before"] = {ds: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for ds, m in srv.global_models.items()}
+                seen["ids"], seen["sizes"] = list(ids), dict(sizes)
+            return orig_agg(srv, ids, sizes, fedavg=fedavg, **kw)
+        srv._aggregate = spy_agg
+        random.seed(F.ROUND_SEED)
+        srv.round = 1
+        srv.update()
+        finals[flag] = {ds: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for ds, m in srv.global_models.items()}
+        if flag:
+            infos = {c.id: AO.ClientInfo(c.dataset, c.task, c.modality) for c in srv.clients}
+            for n, ds in enumerate(srv.global_models):
+                gm = srv.global_models[ds]
+                g = {k: seen["before"][ds][k] for k in gm.required_params().keys()}
+                coef = AO.coefficients(list(g.keys()), srv.param_scope, seen["ids"], seen["sizes"], infos, dataset=ds, task=DATASET_2_TASK[ds],
+                                       modality=DATASET_2_MODALITY[ds], out_modality_scale=F.ROUND_ARGS["out_modality_scales"][n], compensation=True,
+                                       share_scope="all", arg_modalities=srv.args.modalities, fedavg=True)
+                exp = AO.sequential_blend(g, uploads, seen["ids"], coef)
+                for k, v in exp.items():
+                    assert float((seen["models"][ds][k] - v).abs().max()) <= 3e-6 * max(1.0, float(v.abs().max())), (ds, k)
+    differs = 0
+    for ds in finals[True]:
+        for k, v in finals[True][ds].items():
+            if "aux_weight" in k:
+                continue
+            assert float((v - finals[False][ds][k]).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), (ds, k)      # (atomics in the embedding gradients)
+            differs += int(not torch.equal(seen["models"][ds][k], v))
+    assert differs > 0                                     # what was evaluated is not what the round kept
+    FedavgClient._POOL.clear()
+
+
 @pytest.mark.parametrize("path", ["composed", "torch"])
 def test_client_update_with_sgd_matches_the_reference(path):
     """--optimizer SGD (main.py:269: the argument's default) with momentum 0.9, Nesterov, weight decay 1e-3: the device path composes the step
@@ -249,6 +308,19 @@ def test_three_server_rounds_match_the_reference_update():
         for k in srv.global_models["AG_NEWS"].aux_params():
             assert torch.equal(gt[k], gi[k.replace("aux_", "").replace("blockses.1", "blockses.0")]), k
     print("worst per round / model:", report)
+    # a fourth round with --fedavg_eval (fedavgserver.py:796-808): the models _central_evaluate(fedavg=True) sees, and the models the round keeps
+    fe = rec["fedavg_eval_round"]
+    srv.args.fedavg_eval = True
+    seen = {}
+    srv._central_evaluate = lambda fedavg=False: seen.update(fedavg=fedavg, models={ds: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+                                                                                    for ds, m in srv.global_models.items()})
+    srv.round = fe["round"]
+    assert srv.update() == fe["ids"] and seen["fedavg"] is True and srv.curr_lr == pytest.approx(fe["curr_lr"], rel=1e-12)
+    for ds in srv.global_models:
+        w_eval = max(_after_err(seen["models"][ds], fe["evaluated"][ds]).values())
+        w_kept = max(_after_err(srv.global_models[ds].state_dict(), fe["models"][ds]).values())
+        assert w_eval <= 3e-3 and w_kept <= 3e-3, (ds, w_eval, w_kept)
+    srv.args.fedavg_eval = False
     # the fixture's three behaviours are in it
     assert all(F.ROUND_DS[F.ROUND_LAYOUT[i][1]][1] == "txt" for i in rec["rounds"][0]["ids"])
     r2 = rec["rounds"][1]["clients"]["0"]["requires_grad"]
