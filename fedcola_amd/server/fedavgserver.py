@@ -99,6 +99,25 @@ class FedavgServer(BaseServer):
                     names.append(key)
         self.param_scope = agg.init_param_scope(names, shared_param, share_scope)
 
+    def sync_shared_params(self):
+        """fedavgserver.py:160-168 (no caller in the reference): every key whose scope is not 'dataset' is copied from the LAST dataset's model."""
+        sd = self.global_models[self.args.datasets[-1]].state_dict()
+        for model in self.global_models.values():
+            new_sd = model.required_params()
+            for k, v in sd.items():
+                if k in new_sd.keys() and self.param_scope[k] != "dataset":
+                    new_sd[k] = v
+            model.load_state_dict(new_sd, strict=False)
+
+    def _set_loaders(self, datasets):
+        self.server_dataset = datasets[1]                                    # fedavgserver.py:170-171
+
+    def _refine_optim_args(self, args):
+        """fedavgserver.py:432-440."""
+        import inspect
+        required_args = inspect.getfullargspec(torch.optim.__dict__[self.args.optimizer])[0]
+        return {a: getattr(args, a) for a in required_args if hasattr(args, a)}
+
     def _get_algorithm(self, model, **kwargs):
         """fedavgserver.py:241-246: the (dormant) src/algorithm plugin point."""
         cls = import_module(f"..algorithm.{self.args.algorithm}", package=__package__).__dict__[f"{self.args.algorithm.title()}Optimizer"]
@@ -163,9 +182,29 @@ class FedavgServer(BaseServer):
     def _request(self, ids, eval=False, participated=True, retain_model=True, save_raw=False):
         """fedavgserver.py:505-589 (update path).  Each rank trains the sampled clients it owns; sizes/results are exchanged so
         that every rank has the same ``updated_sizes``."""
-        if eval:
-            return None
         dist, rank, world = _dist()
+        if eval:                                                             # fedavgserver.py:522-555: clients' hold-out evaluation
+            if self.args.train_only:
+                return None
+            sizes, results = {}, {}
+            for pos, idx in enumerate(ids):
+                if self._owner_rank(pos, world) != rank:
+                    continue
+                client = self.clients[idx]
+                client.download(self.global_models)                          # (require_model=True: always the current global model)
+                results[client.id] = client.evaluate()
+                sizes[client.id] = len(client.test_set)
+                if not retain_model:
+                    client.model = None
+            if world > 1:
+                gathered = [None] * world
+                dist.all_gather_object(gathered, (sizes, results))
+                sizes, results = {}, {}
+                for s_, r_ in gathered:
+                    sizes.update(s_)
+                    results.update(r_)
+            self.results[self.round][f'clients_evaluated_{"in" if participated else "out"}'] = {str(k): v for k, v in results.items()}
+            return None
         sizes, results = {}, {}
         for pos, idx in enumerate(ids):
             if self._owner_rank(pos, world) != rank:
@@ -375,6 +414,9 @@ class FedavgServer(BaseServer):
         return selected_ids
 
     def evaluate(self, excluded_ids):
+        """fedavgserver.py:858-869: 'local' / 'both' evaluate every client's hold-out set, 'global' / 'both' the server's."""
+        if self.args.eval_type != "global":
+            self._request(range(self.args.K), eval=True, participated=False, retain_model=False, save_raw=self.round == getattr(self.args, "R", -1))
         if self.args.eval_type != "local":
             self._central_evaluate()
 

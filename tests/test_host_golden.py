@@ -473,3 +473,56 @@ def test_server_update_bookkeeping_matches_the_reference_rounds():
             assert trace[int(cid)]["lr"] == pytest.approx(e["lr"], rel=1e-12)
             assert trace[int(cid)]["requires_grad"] == e["requires_grad"], (r, cid)
         assert all(c.model is None for c in clients)
+
+
+def test_server_local_evaluation_branch_and_small_surface_methods():
+    """FedavgServer.evaluate with eval_type 'local' / 'both' (fedavgserver.py:858-869, 522-555): every client downloads the current global model,
+    evaluates its hold-out set, and the results land under clients_evaluated_out; train_only skips it.  Plus the three small methods of the
+    reference's surface: sync_shared_params (:160-168), _set_loaders (:170-171), _refine_optim_args (:432-440)."""
+    from collections import defaultdict
+    import fl_util as F
+    from fedcola_amd.client.fedavgclient import FedavgClient
+    from fedcola_amd.mome import ModalityAgnosticTransformer as M
+    from fedcola_amd.server.fedavgserver import FedavgServer
+    from refstub import RefArgs
+    args = RefArgs(**dict(F.ROUND_ARGS, eval_type="both", train_only=False, R=3))
+    srv = object.__new__(FedavgServer)
+    srv.args, srv._round, srv.writer, srv.results = args, 3, None, defaultdict(dict)
+    srv.global_models = {ds: M(with_aux=True, aux_trained=False, init=False, **F.round_model_kwargs(ds)) for ds in F.ROUND_DS}
+    srv._init_param_scope(args.shared_param, args.share_scope)
+    clients, downloaded = [], []
+    for cid, ds, n in F.ROUND_LAYOUT:
+        cl = object.__new__(FedavgClient)
+        cl._BaseClient__identifier, cl._BaseClient__model = cid, None
+        cl.args, cl.dataset, cl.task, cl.modality, cl.test_set = args, ds, *F.ROUND_DS[ds], list(range(n))
+        cl.evaluate = lambda cl=cl: (downloaded.append((cl.id, cl.model is not None)), {"loss": 0.5 + cl.id, "metrics": {"acc1": 0.1 * cl.id}})[1]
+        clients.append(cl)
+    srv._clients = clients
+    central = []
+    srv._central_evaluate = lambda fedavg=False: central.append(fedavg)
+    srv.evaluate([])
+    assert [c for c, had in downloaded] == [c for c, _, _ in F.ROUND_LAYOUT] and all(had for _, had in downloaded) and central == [False]
+    out = srv.results[3]["clients_evaluated_out"]
+    assert set(out) == {str(c) for c, _, _ in F.ROUND_LAYOUT} and out["4"]["loss"] == 4.5
+    assert all(c.model is None for c in clients)                                   # retain_model=False
+    args.train_only = True
+    downloaded.clear()
+    srv.evaluate([])
+    assert downloaded == []
+    # sync_shared_params: attention keys (scope 'all' here) of every model become the LAST dataset's, the rest stays
+    a = srv.global_models["CIFAR100"]
+    last = srv.global_models[args.datasets[-1]]
+    with torch.no_grad():
+        last.flat.data.uniform_(-1, 1)
+    before = {k: v.clone() for k, v in a.state_dict().items()}
+    srv.sync_shared_params()
+    lsd = last.state_dict()
+    for k, v in a.required_params().items():
+        if k in lsd and srv.param_scope[k] != "dataset":
+            assert torch.equal(v, lsd[k]), k
+        else:
+            assert torch.equal(v, before[k]), k
+    srv._set_loaders((None, {"x": 1}))
+    assert srv.server_dataset == {"x": 1}
+    args.optimizer = "SGD"
+    assert srv._refine_optim_args(args) == {"lr": args.lr, "momentum": args.momentum, "weight_decay": args.weight_decay, "nesterov": args.nesterov}
