@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun) from the repo root: collects everything profiles/rNN/ holds.  usage: tools/collect_profiles.sh r02
-R=${1:-r05}
+R=${1:-r06}
 OUT=gpurun_out/$R
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
